@@ -1,0 +1,112 @@
+/*
+ * pgasr_hip.h -- C ABI of libpgasr_hip.so, the MI355X (gfx950) implementation of the
+ * acoustic-model policy-gradient training hot path of ana-kuznetsova/Policy-Gradient-ASR.
+ *
+ * The reference is pure Python on torch.nn (no FFI of its own), so each
+ * entry point below names the reference call site whose arithmetic it replaces; the Python
+ * host layer (the policy_gradient_asr_amd package) binds these with ctypes and keeps the reference's
+ * module-level names and signatures on top.
+ *
+ * Conventions (all entry points):
+ *   - return value: PGASR_OK (0) or a pgasr_status code; no exceptions cross the ABI;
+ *   - every pointer is a DEVICE pointer owned by the caller unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work (no sync, no
+ *     hipMalloc): workspaces are sized by the *_workspace_bytes queries and caller-allocated;
+ *   - no global mutable state: re-entrant per stream;
+ *   - tensors are dense, row-major, fp32 unless said otherwise; activations are TIME-MAJOR
+ *     (T,B,C) so that one recurrent / CTC step touches one contiguous (B,C) slab;
+ *   - blank = pad = index 0 is the reference's convention (CTCdecoder.py:41, data.py:99) and
+ *     is passed explicitly as `blank`.
+ */
+#ifndef PGASR_HIP_H
+#define PGASR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pgasr_status {
+    PGASR_OK = 0,
+    PGASR_ERR_INVALID_ARG = 1,   /* null pointer, negative size, shape the kernel cannot take */
+    PGASR_ERR_LAUNCH = 2,        /* hipLaunch / runtime error (hipGetLastError != success) */
+    PGASR_ERR_WORKSPACE = 3,     /* workspace null or too small */
+    PGASR_ERR_UNSUPPORTED = 4,   /* size beyond a compiled-in limit (see each function) */
+    PGASR_ERR_TIMEOUT = 5        /* a bounded in-kernel wait gave up (persistent LSTM) */
+} pgasr_status;
+
+#define PGASR_ABI_VERSION 1
+
+int pgasr_abi_version(void);
+const char* pgasr_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------
+ * A5  CTC loss + gradient.  The reference has no call site; the oracle is
+ * torch.nn.functional.ctc_loss composed with log_softmax.  Conventions from CTCdecoder.py:41
+ * (blank=0) and data.py:99 (targets padded with 0).
+ *
+ *   log_probs   (T,B,V) fp32 log-softmax outputs
+ *   targets     (B,Lmax) int32, first target_lengths[b] entries valid
+ *   nll         (B) fp32: -log p(target_b | x_b); +inf when no alignment exists
+ *   grad_logits (T,B,V) fp32: d(sum_b utt_scale[b]*nll_b)/d(logits) = utt_scale[b] *
+ *               (softmax - posterior occupancy); zero for t >= input_lengths[b] and for
+ *               utterances whose nll is +inf.  utt_scale may be NULL (= 1).
+ *   If pg_coef and pg_path are non-NULL the REINFORCE term of pgasr_reinforce_grad is
+ *   added in the same pass (A12):  + pg_coef[b] * (softmax - onehot(pg_path[t,b])).
+ *   Limits: 2*Lmax+1 <= 2048, V <= 64.
+ * ---------------------------------------------------------------------------------------- */
+size_t pgasr_ctc_workspace_bytes(int T, int B, int V, int Lmax);
+int pgasr_ctc_loss_grad(const float* log_probs, const int32_t* targets,
+                        const int32_t* input_lengths, const int32_t* target_lengths,
+                        int T, int B, int V, int Lmax, int blank,
+                        const float* utt_scale, const float* pg_coef, const int32_t* pg_path,
+                        float* nll, float* grad_logits,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A9 / A12  per-frame best label and sampled label.
+ *   scores (T,B,V) fp32 logits or log-probs (softmax is shift invariant).
+ *   greedy_path[t,b] = argmax_v scores[t,b,v], first max wins  (oracle: numpy argmax)
+ *   sample_path[t,b] ~ softmax(scores[t,b,:]) by inverse CDF with
+ *        u = (philox4x32_10(ctr=(t*B+b, offset,0,0), key=(seed_lo,seed_hi)).x >> 8) * 2^-24
+ *   Either output may be NULL.  V <= 64.
+ * ---------------------------------------------------------------------------------------- */
+int pgasr_frame_argmax_sample(const float* scores, int T, int B, int V,
+                              uint64_t seed, uint32_t offset,
+                              int32_t* greedy_path, int32_t* sample_path, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A9  CTC collapse of frame paths: drop repeats, then drop blank, per utterance, for frames
+ * t < lengths[b].  paths (P,T,B) int32 (P stacked path sets, e.g. greedy and sampled);
+ * tokens (P,B,T) int32, token_lengths (P,B) int32.  Bit-exact against
+ * oracle.decode_ref.collapse_path.
+ * ---------------------------------------------------------------------------------------- */
+int pgasr_ctc_collapse(const int32_t* paths, const int32_t* lengths, int P, int T, int B,
+                       int blank, int32_t* tokens, int32_t* token_lengths, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A10  batched Levenshtein distance (metrics.py:4-21: sub = ins = del = 1).
+ *   ref (N,ref_stride) int32 with ref_len (N); hyp (N,hyp_stride) int32 with hyp_len (N);
+ *   dist[n] = ED(ref_n, hyp_n).  If prefix_dist != NULL it is (N,hyp_stride+1) and receives
+ *   ED(ref_n, hyp_n[:i]) for i = 0..hyp_len[n] -- the quantity policy_grad.py:11-15
+ *   differences to form r_t.  Limit: ref_len <= 4095.
+ * ---------------------------------------------------------------------------------------- */
+int pgasr_edit_distance(const int32_t* ref, const int32_t* ref_len, int ref_stride,
+                        const int32_t* hyp, const int32_t* hyp_len, int hyp_stride,
+                        int N, int32_t* dist, int32_t* prefix_dist, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A12  REINFORCE gradient on the logits:
+ *   grad[t,b,v] (+)= coef[b] * (softmax(scores[t,b,:])[v] - (v == path[t,b])),  t < lengths[b]
+ *   and 0 (or unchanged when accumulate != 0) for t >= lengths[b].
+ * ---------------------------------------------------------------------------------------- */
+int pgasr_reinforce_grad(const float* scores, const int32_t* path, const float* coef,
+                         const int32_t* lengths, int T, int B, int V, int accumulate,
+                         float* grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGASR_HIP_H */

@@ -1,0 +1,63 @@
+"""ctypes binding of libpgasr_hip.so (the C ABI declared in include/pgasr_hip.h).
+
+There is NO fallback: if the shared library is missing or a call returns a non-zero
+status this module raises.  Nothing here imports ``oracle``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpgasr_hip.so")
+
+c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
+c_i32p = C.c_void_p
+c_ptr = C.c_void_p
+
+# name -> (restype, argtypes).  Mirrors include/pgasr_hip.h one to one.
+SIGNATURES = {
+    "pgasr_abi_version": (C.c_int, []),
+    "pgasr_status_string": (C.c_char_p, [C.c_int]),
+    "pgasr_ctc_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pgasr_ctc_loss_grad": (C.c_int, [c_f32p, c_i32p, c_i32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_ptr, C.c_size_t, c_ptr]),
+    "pgasr_frame_argmax_sample": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32,
+                                            c_i32p, c_i32p, c_ptr]),
+    "pgasr_ctc_collapse": (C.c_int, [c_i32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, c_ptr]),
+    "pgasr_edit_distance": (C.c_int, [c_i32p, c_i32p, C.c_int, c_i32p, c_i32p, C.c_int, C.c_int,
+                                      c_i32p, c_i32p, c_ptr]),
+    "pgasr_reinforce_grad": (C.c_int, [c_f32p, c_i32p, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       c_f32p, c_ptr]),
+}
+
+
+class PgasrError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise (never fall back) if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PgasrError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C policy_gradient_asr_amd/csrc`.  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pgasr_abi_version() != 1:
+        raise PgasrError("libpgasr_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().pgasr_status_string(status).decode()
+        raise PgasrError(f"{what} failed: status {status} ({msg})")

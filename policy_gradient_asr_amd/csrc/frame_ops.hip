@@ -1,0 +1,143 @@
+// Per-frame label ops on (T,B,V) score tensors for gfx950: argmax / inverse-CDF sample
+// (SURVEY.md §8a A9, A12), CTC collapse of frame paths (A9) and the REINFORCE gradient (A12).
+// All HBM-bound streaming kernels: one 32-lane half-wave per (t,b) row of V <= 64 scores, rows
+// are contiguous so a wave's loads cover one contiguous span.
+#include "common.h"
+
+namespace {
+
+
+// one wave per (t,b) row
+__global__ __launch_bounds__(256) void frame_argmax_sample_kernel(
+    const float* __restrict__ scores, long long rows, int B, int V, uint32_t k0, uint32_t k1,
+    uint32_t offset, int32_t* __restrict__ greedy, int32_t* __restrict__ sample) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float x = (lane < V) ? scores[r * V + lane] : -INFINITY;
+    // argmax, first max wins: reduce (value, index) pairs
+    float bv = x; int bi = (lane < V) ? lane : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (greedy && lane == 0) greedy[r] = bi;
+    if (sample) {
+        const float e = (lane < V) ? __expf(x - bv) : 0.f;
+        // inclusive prefix sum over lanes in label order
+        float c = e;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(c, o, 64);
+            if (lane >= o) c += up;
+        }
+        const float total = __shfl(c, 63, 64);
+        uint32_t rnd[4];
+        philox4x32_10((uint32_t)r, offset, 0u, 0u, k0, k1, rnd);
+        const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
+        const float thr = u * total;
+        // k = number of labels whose inclusive cdf <= u  (oracle: (cdf <= u).sum())
+        const unsigned long long m = __ballot(lane < V && c <= thr);
+        int k = __popcll(m);
+        if (k > V - 1) k = V - 1;
+        if (lane == 0) sample[r] = k;
+    }
+}
+
+// one workgroup per (path set p, utterance b); ballot-compaction over frames
+__global__ __launch_bounds__(256) void ctc_collapse_kernel(
+    const int32_t* __restrict__ paths, const int32_t* __restrict__ lengths, int T, int B, int blank,
+    int32_t* __restrict__ tokens, int32_t* __restrict__ token_lengths) {
+    const int b = blockIdx.x, p = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int32_t* path = paths + (size_t)p * T * B;
+    int32_t* out = tokens + ((size_t)p * B + b) * T;
+    int Tb = lengths ? lengths[b] : T; Tb = Tb < 0 ? 0 : (Tb > T ? T : Tb);
+    __shared__ int wcount[4];
+    __shared__ int base;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < Tb; t0 += 256) {
+        const int t = t0 + tid;
+        int k = blank, prev = -1;
+        if (t < Tb) {
+            k = path[(size_t)t * B + b];
+            prev = (t > 0) ? path[(size_t)(t - 1) * B + b] : -1;
+        }
+        const bool keep = (t < Tb) && (k != blank) && (k != prev);
+        const unsigned long long m = __ballot(keep);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wcount[wid] = __popcll(m);
+        __syncthreads();
+        int woff = base;
+        for (int w = 0; w < wid; ++w) woff += wcount[w];
+        if (keep) out[woff + before] = k;
+        __syncthreads();
+        if (tid == 0) base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+    if (tid == 0) token_lengths[(size_t)p * B + b] = base;
+}
+
+// one wave per (t,b) row
+__global__ __launch_bounds__(256) void reinforce_grad_kernel(
+    const float* __restrict__ scores, const int32_t* __restrict__ path, const float* __restrict__ coef,
+    const int32_t* __restrict__ lengths, long long rows, int B, int V, int accumulate,
+    float* __restrict__ grad) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int t = (int)(r / B), b = (int)(r % B);
+    const int Tb = lengths ? lengths[b] : 0x7fffffff;
+    if (t >= Tb) { if (!accumulate && lane < V) grad[r * V + lane] = 0.f; return; }
+    const float x = (lane < V) ? scores[r * V + lane] : -INFINITY;
+    const float mx = wave_max(x);
+    const float e = (lane < V) ? __expf(x - mx) : 0.f;
+    const float tot = wave_sum(e);
+    const int k = path[r];
+    const float g = coef[b] * (e / tot - (lane == k ? 1.f : 0.f));
+    if (lane < V) {
+        if (accumulate) grad[r * V + lane] += g; else grad[r * V + lane] = g;
+    }
+}
+
+}  // namespace
+
+extern "C" int pgasr_frame_argmax_sample(const float* scores, int T, int B, int V,
+                                         uint64_t seed, uint32_t offset,
+                                         int32_t* greedy_path, int32_t* sample_path, void* stream) {
+    if (!scores || T <= 0 || B <= 0 || V <= 0) return PGASR_ERR_INVALID_ARG;
+    if (V > 64) return PGASR_ERR_UNSUPPORTED;
+    if (!greedy_path && !sample_path) return PGASR_OK;
+    const long long rows = (long long)T * B;
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    hipLaunchKernelGGL(frame_argmax_sample_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       scores, rows, B, V, (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), offset,
+                       greedy_path, sample_path);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
+
+extern "C" int pgasr_ctc_collapse(const int32_t* paths, const int32_t* lengths, int P, int T, int B,
+                                  int blank, int32_t* tokens, int32_t* token_lengths, void* stream) {
+    if (!paths || !tokens || !token_lengths || P <= 0 || T <= 0 || B <= 0) return PGASR_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B, P), dim3(256), 0, (hipStream_t)stream,
+                       paths, lengths, T, B, blank, tokens, token_lengths);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
+
+extern "C" int pgasr_reinforce_grad(const float* scores, const int32_t* path, const float* coef,
+                                    const int32_t* lengths, int T, int B, int V, int accumulate,
+                                    float* grad, void* stream) {
+    if (!scores || !path || !coef || !grad || T <= 0 || B <= 0 || V <= 0) return PGASR_ERR_INVALID_ARG;
+    if (V > 64) return PGASR_ERR_UNSUPPORTED;
+    const long long rows = (long long)T * B;
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    hipLaunchKernelGGL(reinforce_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       scores, path, coef, lengths, rows, B, V, accumulate, grad);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
