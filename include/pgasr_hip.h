@@ -106,6 +106,82 @@ int pgasr_reinforce_grad(const float* scores, const int32_t* path, const float* 
                          const int32_t* lengths, int T, int B, int V, int accumulate,
                          float* grad, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Dense contractions (A1-A4 and their gradients).  fp32 in, fp32 accumulate on the matrix cores
+ * (v_mfma_f32_32x32x2_f32, bit-equal to an fmaf chain).
+ *
+ *   C[b] (M x N, ldc) = epilogue( alpha * opA(A[b]) * opB(B[b]) )     b = 0..batch-1
+ *   opA(A) = A (M x K row-major, lda) or, transA != 0, A stored K x M;  opB likewise (transB != 0:
+ *   B stored N x K, i.e. torch's Linear weight layout).
+ *   sum_batches != 0: the batch results are summed into the single C (partial slabs in workspace,
+ *   reduced in index order); splitk > 1 splits K the same way.  workspace bytes:
+ *   pgasr_gemm_workspace_bytes.  epilogue: + bias[n] + bias2[n]; act 1 = leaky_relu(slope)
+ *   (model.py:50); dact_y != NULL multiplies by d leaky_relu evaluated on dact_y (same layout as C);
+ *   accumulate != 0 adds to C.  norm_operand 1/2 applies (x - shift[b]) * scale[b] to A/B while
+ *   the tile is loaded: the per-utterance InstanceNorm2d of model.py:37,48 fused into the affine.
+ * ---------------------------------------------------------------------------------------- */
+size_t pgasr_gemm_workspace_bytes(int M, int N, int batch, int splitk, int sum_batches);
+int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
+                   const float* A, int lda, long long strideA,
+                   const float* B, int ldb, long long strideB,
+                   float* C, int ldc, long long strideC,
+                   int batch, int sum_batches, int splitk,
+                   const float* bias, const float* bias2, int act, float slope, int accumulate,
+                   const float* dact_y, int norm_operand, const float* shift, const float* scale,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* column sums of X (rows x cols, leading dim ld) -> out (and out2 if non-NULL): bias gradients. */
+size_t pgasr_colsum_workspace_bytes(int rows, int cols);
+int pgasr_colsum_f32(const float* X, int rows, int cols, int ld, float* out, float* out2, int accumulate,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* A1: per-utterance mean and 1/sqrt(var+eps) over all F*T values of x (B,F,T), biased variance,
+ * padding included (model.py:37,48; nn.InstanceNorm2d on (B,1,F,T)). */
+int pgasr_instnorm_stats(const float* x, int B, int F, int T, float eps, float* mean, float* rstd,
+                         void* stream);
+
+/* A4: row-wise log_softmax of logits (rows, V), V <= 64 (the commented head of model.py:166-167;
+ * consumer contract model.py:323). */
+int pgasr_log_softmax_rows(const float* logits, long long rows, int V, float* log_probs, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A3  bidirectional LSTM layer, H = 256 per direction (model.py:39-44), packed-sequence semantics
+ * of model.py:52-55: per-utterance lengths, the reverse direction starts at each utterance's own
+ * last frame, outputs are zero past the length.
+ *
+ * pgasr_lstm_pack_weights: torch-layout parameters of the two directions (weight_ih (4H,in),
+ *   weight_hh (4H,H), bias_ih, bias_hh (4H); gate rows i|f|g|o) ->
+ *     wih_perm (2*4H, in) and bias_perm (2*4H) in column order dir*4H + unit*4 + gate
+ *     (bias_perm = bias_ih + bias_hh), and the two register-resident bf16 hi/lo W_hh packs
+ *     (pgasr_lstm_pack_bytes each) the sweeps load once.
+ * pgasr_lstm_layer_fwd: gates (T,B,2,H,4) holds xproj = X * wih_perm^T + bias_perm on entry and
+ *   the activations (i,f,g,o) on exit; out (T,B,2H) = h; cbuf (T,B,2,H) = c.
+ * pgasr_lstm_layer_bwd: dout (T,B,2H) -> gates overwritten in place by d(pre-activation gates);
+ *   the caller forms dX = dgates * wih_perm, dW_ih = dgates^T X, dW_hh = dgates^T h_prev with
+ *   pgasr_gemm_f32 and maps them back with pgasr_lstm_unpack_grads.
+ * The sweeps are persistent kernels: 16 workgroups per (direction, 16-utterance group) that hand
+ * h_t / dgates_t to each other through HBM every step (write-through stores + one counter).
+ * Limit: B <= 128.  workspace (pgasr_lstm_workspace_bytes) holds exchange buffers, counters and an
+ * error word (offset: pgasr_lstm_error_offset) that is set when a bounded wait times out.
+ * ---------------------------------------------------------------------------------------- */
+size_t pgasr_lstm_pack_bytes(int which);
+int pgasr_lstm_pack_weights(const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f,
+                            const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                            int in_dim, float* wih_perm, float* bias_perm,
+                            void* whh_pack_fwd, void* whh_pack_bwd, void* stream);
+int pgasr_lstm_unpack_grads(const float* dwih_perm, const float* dbias_perm, const float* dwhh_perm, int in_dim,
+                            float* dw_ih_f, float* dw_hh_f, float* db_ih_f, float* db_hh_f,
+                            float* dw_ih_r, float* dw_hh_r, float* db_ih_r, float* db_hh_r,
+                            int accumulate, void* stream);
+size_t pgasr_lstm_workspace_bytes(int T, int B, int backward);
+int pgasr_lstm_error_offset(int B, int backward, size_t* offset);
+int pgasr_lstm_layer_fwd(float* gates, float* out, float* cbuf, const void* whh_pack_fwd,
+                         const int32_t* lengths, int T, int B,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int pgasr_lstm_layer_bwd(float* gates, const float* out, const float* cbuf, const float* dout,
+                         const void* whh_pack_bwd, const int32_t* lengths, int T, int B,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,20 +76,16 @@ def encoder_forward_torch(p, x, mask, packed=True):
     h = instance_norm(x).transpose(1, 2)                      # (B,T,F)
     h = F.leaky_relu(F.linear(h, p["input_layer.weight"], p["input_layer.bias"]))
     lengths = mask.sum(dim=1).to(torch.int64).cpu()
-    lstm = torch.nn.LSTM(D_IN, H, N_LAYERS, bidirectional=True, batch_first=True)
-    lstm = lstm.to(x.dtype)
-    sd = {k[len("blstm."):]: v for k, v in p.items() if k.startswith("blstm.")}
-    # parameters may require grad: bind them instead of copying
-    for name, v in sd.items():
-        lstm._parameters[name] = v if isinstance(v, torch.nn.Parameter) else torch.nn.Parameter(v, requires_grad=v.requires_grad)
-    lstm._flat_weights = [lstm._parameters[n] for n in lstm._flat_weights_names]
+    lstm = torch.nn.LSTM(D_IN, H, N_LAYERS, bidirectional=True, batch_first=True).to(x.dtype)
     lstm.eval()
+    # run the module with OUR tensors as its parameters so gradients flow back to ``p``
+    sd = {k[len("blstm."):]: v for k, v in p.items() if k.startswith("blstm.")}
     if packed:
         pk = pack_padded_sequence(h, lengths, enforce_sorted=False, batch_first=True)
-        out, _ = lstm(pk)
+        out, _ = torch.func.functional_call(lstm, sd, (pk,))
         out, _ = pad_packed_sequence(out, total_length=T, batch_first=True)
     else:
-        out, _ = lstm(h)
+        out, _ = torch.func.functional_call(lstm, sd, (h,))
     return out
 
 

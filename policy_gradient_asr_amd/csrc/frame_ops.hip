@@ -103,7 +103,29 @@ __global__ __launch_bounds__(256) void reinforce_grad_kernel(
     }
 }
 
+// one wave per row: log_softmax over V <= 64 labels
+__global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ x, long long rows, int V,
+                                                               float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float v = (lane < V) ? x[r * V + lane] : -INFINITY;
+    const float mx = wave_max(v);
+    const float e = (lane < V) ? __expf(v - mx) : 0.f;
+    const float lse = mx + __logf(wave_sum(e));
+    if (lane < V) y[r * V + lane] = v - lse;
+}
+
 }  // namespace
+
+extern "C" int pgasr_log_softmax_rows(const float* logits, long long rows, int V, float* log_probs, void* stream) {
+    if (!logits || !log_probs || rows <= 0 || V <= 0) return PGASR_ERR_INVALID_ARG;
+    if (V > 64) return PGASR_ERR_UNSUPPORTED;
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    hipLaunchKernelGGL(log_softmax_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, rows, V, log_probs);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
 
 extern "C" int pgasr_frame_argmax_sample(const float* scores, int T, int B, int V,
                                          uint64_t seed, uint32_t offset,

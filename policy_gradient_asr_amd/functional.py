@@ -1,0 +1,161 @@
+"""torch.autograd glue over the HIP kernels.  Activations are time-major (T,B,C).
+No function here has a CPU path: tensors must be on the MI355X."""
+import torch
+
+from . import hipops
+
+HID = hipops.HID
+LEAKY_SLOPE = 0.01   # F.leaky_relu default, model.py:50
+
+
+def _pick_splitk(M, N, K, target_wgs=256):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    sk = max(1, min(64, target_wgs // max(tiles, 1)))
+    while sk > 1 and K // sk < 256:
+        sk //= 2
+    return max(sk, 1)
+
+
+class InstNormAffineFn(torch.autograd.Function):
+    """model.py:48-50: InstanceNorm2d over the (F,T) plane -> Linear(F,512) -> leaky_relu.
+    x (B,F,T) -> y (T,B,N).  The normalisation is applied while the GEMM loads its tile."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, consumer_applies_dact=False):
+        """consumer_applies_dact: the op consuming y multiplies its input gradient by
+        leaky'(y) itself (BLSTMLayerFn's dact_y epilogue), so backward must not repeat it."""
+        B, F, T = x.shape
+        N = weight.shape[0]
+        x = x.contiguous(); weight = weight.contiguous(); bias = bias.contiguous()
+        ctx.consumer_applies_dact = bool(consumer_applies_dact)
+        mean, rstd = hipops.instnorm_stats(x, 1e-5)
+        y = torch.empty(T, B, N, dtype=torch.float32, device=x.device)
+        hipops.gemm(x, weight, y, M=T, N=N, K=F, transA=True, transB=True, lda=T, ldb=F, ldc=B * N,
+                    strideA=F * T, strideB=0, strideC=N, batch=B, bias=bias, act=1, slope=LEAKY_SLOPE,
+                    norm_operand=1, shift=mean, scale=rstd)
+        ctx.save_for_backward(x, weight, mean, rstd, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, rstd, y = ctx.saved_tensors
+        B, F, T = x.shape
+        N = weight.shape[0]
+        # d(pre-activation) = dy * leaky'(y)   (sign(y) == sign(pre))
+        if ctx.consumer_applies_dact:
+            dpre = dy.contiguous()
+        else:
+            dpre = torch.where(y > 0, dy, dy * LEAKY_SLOPE).contiguous()
+        return (None, *InstNormAffineFn.param_grads(x, mean, rstd, dpre, N), None)
+
+    @staticmethod
+    def param_grads(x, mean, rstd, dpre, N):
+        B, F, T = x.shape
+        dW = torch.empty(N, F, dtype=torch.float32, device=x.device)
+        hipops.gemm(dpre, x, dW, M=N, N=F, K=T, transA=True, transB=True, lda=B * N, ldb=T, ldc=F,
+                    strideA=N, strideB=F * T, strideC=0, batch=B, sum_batches=True, norm_operand=2,
+                    shift=mean, scale=rstd)
+        db = torch.empty(N, dtype=torch.float32, device=x.device)
+        hipops.colsum(dpre, T * B, N, N, db)
+        return dW, db
+
+
+class LinearFn(torch.autograd.Function):
+    """y (rows,N) = x (rows,K) W^T + b   (the CTC head)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        shp = x.shape
+        x2 = x.contiguous().view(-1, shp[-1])
+        rows, K = x2.shape
+        N = weight.shape[0]
+        weight = weight.contiguous()
+        y = torch.empty(rows, N, dtype=torch.float32, device=x.device)
+        hipops.gemm(x2, weight, y, M=rows, N=N, K=K, transB=True, bias=bias.contiguous())
+        ctx.save_for_backward(x2, weight)
+        ctx.shp = shp
+        return y.view(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        rows, K = x2.shape
+        N = weight.shape[0]
+        dy2 = dy.contiguous().view(rows, N)
+        dx = torch.empty(rows, K, dtype=torch.float32, device=dy.device)
+        hipops.gemm(dy2, weight, dx, M=rows, N=K, K=N)
+        dW = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+        hipops.gemm(dy2, x2, dW, M=N, N=K, K=rows, transA=True, lda=N, splitk=_pick_splitk(N, K, rows))
+        db = torch.empty(N, dtype=torch.float32, device=dy.device)
+        hipops.colsum(dy2, rows, N, N, db)
+        return dx.view(ctx.shp), dW, db
+
+
+class LogSoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits):
+        lp = hipops.log_softmax_rows(logits.contiguous())
+        ctx.save_for_backward(lp)
+        return lp
+
+    @staticmethod
+    def backward(ctx, g):
+        (lp,) = ctx.saved_tensors
+        return g - torch.exp(lp) * g.sum(dim=-1, keepdim=True)
+
+
+class BLSTMLayerFn(torch.autograd.Function):
+    """One bidirectional LSTM layer (model.py:39-44) on a time-major input (T,B,I) with
+    per-utterance lengths (packed-sequence semantics of model.py:52-55)."""
+
+    @staticmethod
+    def forward(ctx, x, lengths, dact_y, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        T, B, I = x.shape
+        x = x.contiguous()
+        params = [p.contiguous() for p in (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)]
+        wih_perm, bias_perm, pack_f, pack_b = hipops.lstm_pack(params, I)
+        G = 2 * 4 * HID
+        gates = torch.empty(T, B, G, dtype=torch.float32, device=x.device)
+        hipops.gemm(x, wih_perm, gates, M=T * B, N=G, K=I, transB=True, bias=bias_perm)
+        out = torch.empty(T, B, 2 * HID, dtype=torch.float32, device=x.device)
+        cbuf = torch.empty(T, B, 2 * HID, dtype=torch.float32, device=x.device)
+        hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B)
+        ctx.save_for_backward(x, lengths, gates, out, cbuf, wih_perm, pack_b, dact_y if dact_y is not None else x.new_empty(0))
+        ctx.has_dact = dact_y is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, lengths, gates, out, cbuf, wih_perm, pack_b, dact_y = ctx.saved_tensors
+        T, B, I = x.shape
+        G = 2 * 4 * HID
+        dev = x.device
+        dout = dout.contiguous()
+        hipops.lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B)   # gates := dgates
+        dg = gates
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(T, B, I, dtype=torch.float32, device=dev)
+            hipops.gemm(dg, wih_perm, dx, M=T * B, N=I, K=G, dact_y=dact_y if ctx.has_dact else None,
+                        slope=LEAKY_SLOPE)
+        dwih = torch.empty(G, I, dtype=torch.float32, device=dev)
+        hipops.gemm(dg, x, dwih, M=G, N=I, K=T * B, transA=True, lda=G, splitk=_pick_splitk(G, I, T * B))
+        dbias = torch.empty(G, dtype=torch.float32, device=dev)
+        hipops.colsum(dg, T * B, G, G, dbias)
+        dwhh = torch.zeros(2, 4 * HID, HID, dtype=torch.float32, device=dev)
+        if T > 1:
+            # dW_hh[d] = sum_t dgates_t[d]^T h_{prev(t)}[d];  prev = t-1 (fwd) / t+1 (rev); one launch, 2 batches
+            K = (T - 1) * B
+            hipops.gemm(dg, out, dwhh, M=4 * HID, N=HID, K=K, transA=True, lda=G, ldb=2 * HID, ldc=HID,
+                        a_off=B * G, b_off=0, strideA=4 * HID - B * G, strideB=B * 2 * HID + HID,
+                        strideC=4 * HID * HID, batch=2, splitk=_pick_splitk(4 * HID, HID, K, 128))
+        gl = [torch.empty(4 * HID, I, device=dev), torch.empty(4 * HID, HID, device=dev),
+              torch.empty(4 * HID, device=dev), torch.empty(4 * HID, device=dev),
+              torch.empty(4 * HID, I, device=dev), torch.empty(4 * HID, HID, device=dev),
+              torch.empty(4 * HID, device=dev), torch.empty(4 * HID, device=dev)]
+        hipops.lstm_unpack_grads(dwih, dbias, dwhh, I, gl)
+        return (dx, None, None, *gl)
+
+
+def blstm_layer(x, lengths, params, dact_y=None):
+    return BLSTMLayerFn.apply(x, lengths, dact_y, *params)

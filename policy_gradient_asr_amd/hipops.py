@@ -116,3 +116,127 @@ def reinforce_grad(scores, path, coef, lengths, out=None, accumulate=False):
                                   _p(out), _stream())
     _lib.check(st, "pgasr_reinforce_grad")
     return out
+
+
+# ------------------------------------------------------------------------------------------
+# dense contractions
+# ------------------------------------------------------------------------------------------
+def gemm(A, B, C, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=None, alpha=1.0,
+         strideA=0, strideB=0, strideC=0, batch=1, sum_batches=False, splitk=1, bias=None, bias2=None,
+         act=0, slope=0.01, accumulate=False, dact_y=None, norm_operand=0, shift=None, scale=None,
+         a_off=0, b_off=0, c_off=0):
+    """Raw strided GEMM on device tensors (element offsets a_off/b_off/c_off into A/B/C).
+    See include/pgasr_hip.h for the contract."""
+    lib = _lib.load()
+    for t, nm in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (bias2, "bias2"), (dact_y, "dact_y"),
+                  (shift, "shift"), (scale, "scale")):
+        if t is not None:
+            if not t.is_cuda or t.dtype != torch.float32:
+                raise _lib.PgasrError(f"gemm operand {nm} must be a float32 GPU tensor")
+    lda = lda if lda is not None else (M if transA else K)
+    ldb = ldb if ldb is not None else (K if transB else N)
+    ldc = ldc if ldc is not None else N
+    nbytes = lib.pgasr_gemm_workspace_bytes(M, N, batch, splitk, int(sum_batches))
+    ws = _workspace(nbytes, C.device, "gemm") if nbytes else None
+    st = lib.pgasr_gemm_f32(int(transA), int(transB), M, N, K, float(alpha),
+                            A.data_ptr() + 4 * a_off, lda, int(strideA), B.data_ptr() + 4 * b_off, ldb, int(strideB),
+                            C.data_ptr() + 4 * c_off, ldc, int(strideC), batch, int(sum_batches), splitk,
+                            _p(bias), _p(bias2), act, float(slope), int(accumulate), _p(dact_y),
+                            norm_operand, _p(shift), _p(scale), _p(ws), ws.numel() if ws is not None else 0, _stream())
+    _lib.check(st, "pgasr_gemm_f32")
+    return C
+
+
+def colsum(X, rows, cols, ld, out, out2=None, accumulate=False):
+    lib = _lib.load()
+    nbytes = lib.pgasr_colsum_workspace_bytes(rows, cols)
+    ws = _workspace(nbytes, X.device, "colsum")
+    st = lib.pgasr_colsum_f32(_p(X), rows, cols, ld, _p(out), _p(out2), int(accumulate), _p(ws), ws.numel(), _stream())
+    _lib.check(st, "pgasr_colsum_f32")
+    return out
+
+
+def instnorm_stats(x, eps=1e-5):
+    lib = _lib.load()
+    _req(x, torch.float32, "x")
+    B, F, T = x.shape
+    mean = torch.empty(B, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B, dtype=torch.float32, device=x.device)
+    _lib.check(lib.pgasr_instnorm_stats(_p(x), B, F, T, float(eps), _p(mean), _p(rstd), _stream()), "pgasr_instnorm_stats")
+    return mean, rstd
+
+
+def log_softmax_rows(logits):
+    lib = _lib.load()
+    _req(logits, torch.float32, "logits")
+    V = logits.shape[-1]
+    out = torch.empty_like(logits)
+    _lib.check(lib.pgasr_log_softmax_rows(_p(logits), logits.numel() // V, V, _p(out), _stream()), "pgasr_log_softmax_rows")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# LSTM layer
+# ------------------------------------------------------------------------------------------
+HID = 256
+
+
+def lstm_pack(params, in_dim):
+    """params: 8 tensors (w_ih, w_hh, b_ih, b_hh) x (fwd, rev) -> (wih_perm, bias_perm, pack_f, pack_b)."""
+    lib = _lib.load()
+    dev = params[0].device
+    for t in params:
+        _req(t, torch.float32, "lstm parameter")
+    wih_perm = torch.empty(2 * 4 * HID, in_dim, dtype=torch.float32, device=dev)
+    bias_perm = torch.empty(2 * 4 * HID, dtype=torch.float32, device=dev)
+    nb = lib.pgasr_lstm_pack_bytes(0)
+    pack_f = torch.empty(nb, dtype=torch.uint8, device=dev)
+    pack_b = torch.empty(nb, dtype=torch.uint8, device=dev)
+    st = lib.pgasr_lstm_pack_weights(*[_p(t) for t in params], in_dim, _p(wih_perm), _p(bias_perm),
+                                     _p(pack_f), _p(pack_b), _stream())
+    _lib.check(st, "pgasr_lstm_pack_weights")
+    return wih_perm, bias_perm, pack_f, pack_b
+
+
+def lstm_unpack_grads(dwih_perm, dbias_perm, dwhh_perm, in_dim, grads, accumulate=False):
+    lib = _lib.load()
+    st = lib.pgasr_lstm_unpack_grads(_p(dwih_perm), _p(dbias_perm), _p(dwhh_perm), in_dim,
+                                     *[_p(g) for g in grads], int(accumulate), _stream())
+    _lib.check(st, "pgasr_lstm_unpack_grads")
+
+
+_lstm_err_checks = []
+
+
+def _lstm_ws(T, B, backward, device):
+    lib = _lib.load()
+    nbytes = lib.pgasr_lstm_workspace_bytes(T, B, int(backward))
+    return _workspace(nbytes, device, "lstm_bwd" if backward else "lstm_fwd")
+
+
+def lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B):
+    lib = _lib.load()
+    ws = _lstm_ws(T, B, False, gates.device)
+    st = lib.pgasr_lstm_layer_fwd(_p(gates), _p(out), _p(cbuf), _p(pack_f), _p(lengths), T, B, _p(ws), ws.numel(), _stream())
+    _lib.check(st, "pgasr_lstm_layer_fwd")
+    return ws
+
+
+def lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B):
+    lib = _lib.load()
+    ws = _lstm_ws(T, B, True, gates.device)
+    st = lib.pgasr_lstm_layer_bwd(_p(gates), _p(out), _p(cbuf), _p(dout), _p(pack_b), _p(lengths), T, B,
+                                  _p(ws), ws.numel(), _stream())
+    _lib.check(st, "pgasr_lstm_layer_bwd")
+    return ws
+
+
+def lstm_check_error(ws, B, backward):
+    """Host-side check (synchronises): raises if a persistent sweep timed out."""
+    import ctypes
+    lib = _lib.load()
+    off = ctypes.c_size_t(0)
+    _lib.check(lib.pgasr_lstm_error_offset(B, int(backward), ctypes.byref(off)), "pgasr_lstm_error_offset")
+    flag = int(ws[off.value:off.value + 4].view(torch.int32).item())
+    if flag != 0:
+        raise _lib.PgasrError("persistent LSTM sweep timed out waiting for its cluster (status 5)")

@@ -1,0 +1,143 @@
+"""GEMM / affine / LSTM / head parity against torch-CPU (the oracle's arithmetic), through the
+C ABI.  Tolerance 1e-3 relative on outputs and gradients (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+@pytest.mark.parametrize("tA,tB,M,N,K", [
+    (0, 0, 128, 128, 16), (0, 1, 300, 200, 77), (1, 0, 129, 65, 40), (1, 1, 64, 257, 128),
+    (0, 1, 1000, 29, 512), (0, 0, 500, 512, 29), (1, 0, 29, 512, 3000),
+])
+def test_gemm_layouts(tA, tB, M, N, K):
+    from policy_gradient_asr_amd import hipops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if tA else (M, K), generator=g)
+    B = torch.randn((N, K) if tB else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    want = (A.t() if tA else A).double() @ (B.t() if tB else B).double() + bias.double()
+    C = torch.empty(M, N, device=DEV)
+    hipops.gemm(A.to(DEV), B.to(DEV), C, M, N, K, transA=bool(tA), transB=bool(tB), bias=bias.to(DEV))
+    assert rel_err(C.cpu(), want) < 1e-5
+    # split-K + accumulate + leaky epilogue
+    C2 = torch.ones(M, N, device=DEV)
+    hipops.gemm(A.to(DEV), B.to(DEV), C2, M, N, K, transA=bool(tA), transB=bool(tB), splitk=3, bias=bias.to(DEV),
+                act=1, slope=0.01, accumulate=True)
+    want2 = torch.nn.functional.leaky_relu(want, 0.01) + 1.0
+    assert rel_err(C2.cpu(), want2) < 1e-5
+
+
+def test_instnorm_affine_fwd_bwd():
+    from policy_gradient_asr_amd import functional as Fh
+    B, F, T, N = 3, 80, 50, 512
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, F, T, generator=g) * 3 + 1.5
+    W = torch.randn(N, F, generator=g) * 0.1; b = torch.randn(N, generator=g) * 0.1
+    Wc = W.clone().requires_grad_(True); bc = b.clone().requires_grad_(True)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.linear(model_ref.instance_norm(x).transpose(1, 2), Wc, bc))
+    dy = torch.randn(T, B, N, generator=g)
+    ref.transpose(0, 1).backward(dy)
+    Wg = W.to(DEV).requires_grad_(True); bg = b.to(DEV).requires_grad_(True)
+    y = Fh.InstNormAffineFn.apply(x.to(DEV), Wg, bg)
+    y.backward(dy.to(DEV))
+    assert rel_err(y.detach().cpu(), ref.detach().transpose(0, 1)) < 1e-5
+    assert rel_err(Wg.grad.cpu(), Wc.grad) < 1e-4
+    assert rel_err(bg.grad.cpu(), bc.grad) < 1e-4
+
+
+def _lstm_case(T, B, lens, seed, in_dim=512):
+    g = torch.Generator().manual_seed(seed)
+    lstm = torch.nn.LSTM(in_dim, 256, 1, bidirectional=True)
+    x = torch.randn(T, B, in_dim, generator=g)
+    dy = torch.randn(T, B, 512, generator=g)
+    lengths = torch.tensor(lens, dtype=torch.int64)
+    for b, n in enumerate(lens):
+        dy[n:, b] = 0  # padded outputs carry no gradient in the packed reference either
+    return lstm, x, dy, lengths
+
+
+@pytest.mark.parametrize("T,B,lens", [
+    (5, 2, [5, 5]), (40, 4, [40, 33, 1, 17]), (64, 16, [64] * 16), (30, 19, list(range(30, 11, -1))),
+    (200, 32, [200] * 32),
+])
+def test_blstm_layer_vs_torch_cpu(T, B, lens):
+    from policy_gradient_asr_amd import functional as Fh
+    from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    lstm, x, dy, lengths = _lstm_case(T, B, lens, seed=T + B)
+    xr = x.clone().requires_grad_(True)
+    pk = pack_padded_sequence(xr, lengths, enforce_sorted=False)
+    out, _ = lstm(pk)
+    out, _ = pad_packed_sequence(out, total_length=T)
+    out.backward(dy)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0",
+             "weight_ih_l0_reverse", "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+    params = [getattr(lstm, n).detach().to(DEV).requires_grad_(True) for n in names]
+    xg = x.to(DEV).requires_grad_(True)
+    y = Fh.blstm_layer(xg, lengths.to(torch.int32).to(DEV), params)
+    y.backward(dy.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(y.detach().cpu(), out.detach()) < 1e-4
+    for b, n in enumerate(lens):
+        assert torch.all(y[n:, b] == 0)
+    assert rel_err(xg.grad.cpu(), xr.grad) < 1e-3
+    for n, p in zip(names, params):
+        assert rel_err(p.grad.cpu(), getattr(lstm, n).grad) < 1e-3, n
+
+
+def test_encoder_matches_reference_golden(golden_dir):
+    """Encoder on the MI355X vs the reference model.Encoder outputs (tests/golden)."""
+    from policy_gradient_asr_amd.model import Encoder
+    z = np.load(os.path.join(golden_dir, "encoder_cases.npz"))
+    p = model_ref.init_params(n_feats=120, vocab=29, seed=0)
+    enc = Encoder()
+    enc.load_state_dict({k: v for k, v in p.items() if not k.startswith("head.")}, strict=True)
+    assert list(enc.state_dict().keys()) == list(z["names"])
+    enc = enc.to(DEV).eval()
+    for cid in range(3):
+        x = torch.from_numpy(z[f"x{cid}"]).to(DEV); mask = torch.from_numpy(z[f"mask{cid}"]).to(DEV)
+        with torch.no_grad():
+            y = enc(x, mask)
+        assert y.shape == z[f"y{cid}"].shape
+        assert rel_err(y.cpu(), z[f"y{cid}"]) < 1e-3
+        lens = mask.sum(1).int().tolist()
+        for b, n in enumerate(lens):
+            assert torch.all(y[b, n:] == 0)
+
+
+def test_seq2seq_logprobs_and_grads_vs_oracle():
+    from policy_gradient_asr_amd.model import Seq2Seq
+    B, F, T, V = 4, 80, 60, 29
+    p = model_ref.init_params(n_feats=F, vocab=V, seed=3)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, F, T, generator=g)
+    lens = [60, 41, 60, 25]
+    mask = torch.zeros(B, T)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1; x[b, :, n:] = 0
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    enc = model_ref.encoder_forward_torch(pr, x, mask)
+    lp_ref = model_ref.head_forward_torch(pr, enc)
+    w = torch.randn(T, B, V, generator=g) * mask.t()[:, :, None]
+    (lp_ref * w).sum().backward()
+    m = Seq2Seq(V, n_feats=F)
+    sd = {("encoder." + k if not k.startswith("head.") else k): v for k, v in p.items()}
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    lp = m(x.to(DEV), None, mask.to(DEV), DEV)
+    (lp * w.to(DEV)).sum().backward()
+    assert rel_err(lp.detach().cpu(), lp_ref.detach()) < 1e-3
+    for k, v in m.named_parameters():
+        rk = k[len("encoder."):] if k.startswith("encoder.") else k
+        assert rel_err(v.grad.cpu(), pr[rk].grad) < 2e-3, k
