@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py --gpus N --steps K --warmup W : utterances/sec of one policy-gradient train step
+(BASELINE.json metric) on synthetic (B=32 per GPU, T=1000, F=80, V=29) data, one process per GPU.
+Prints ONE JSON line on rank 0 (contract in the task statement)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+B_PER_GPU, T, F, V, L = 32, 1000, 80, 29, 100
+
+
+def synth_batch(device, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B_PER_GPU, F, T, generator=g)
+    targets = torch.randint(1, V, (B_PER_GPU, L), generator=g)
+    fmask = torch.ones(B_PER_GPU, T)
+    tmask = torch.ones(B_PER_GPU, L, dtype=torch.int64)
+    return [t.to(device) for t in (x, targets, fmask, tmask)]
+
+
+def cpu_baseline(steps=1):
+    """The oracle's train step (torch-CPU model + ctc_loss + numpy decode/edit distance) on this
+    box's host cores.  Lengths are all T, so the unpacked LSTM is the same arithmetic as the
+    reference's packed call (SURVEY §6 variant ii)."""
+    import numpy as np
+    from oracle import model_ref, decode_ref
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))   # the GPU box gives one GPU a 16-core share
+    torch.set_num_threads(cores)
+    p = {k: v.clone().requires_grad_(True) for k, v in model_ref.init_params(F, V, 0).items()}
+    opt = torch.optim.Adam(list(p.values()), lr=5e-4)
+    x, targets, fmask, tmask = synth_batch("cpu", 0)
+    il = torch.full((B_PER_GPU,), T, dtype=torch.long); tl = torch.full((B_PER_GPU,), L, dtype=torch.long)
+    times = []
+    for s in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        enc = model_ref.encoder_forward_torch(p, x, fmask, packed=False)
+        logits = model_ref.head_logits_torch(p, enc)
+        lp = torch.log_softmax(logits, 2)
+        ctc = torch.nn.functional.ctc_loss(lp, targets, il, tl, blank=0, reduction="mean")
+        with torch.no_grad():
+            ln = logits.detach().numpy()
+            paths, _, _ = decode_ref.sample_paths(ln, seed=0, offset=s)
+            greedy = decode_ref.greedy_decode(ln)
+            adv = np.zeros(B_PER_GPU)
+            for b in range(B_PER_GPU):
+                y = targets[b].tolist()
+                rs = -decode_ref.edit_dist(y, decode_ref.collapse_path(paths[:, b]))[0] / L
+                rg = -decode_ref.edit_dist(y, greedy[b])[0] / L
+                adv[b] = rs - rg
+        lps = lp.gather(2, torch.from_numpy(paths).unsqueeze(-1)).squeeze(-1).sum(0)
+        loss = ctc - (torch.from_numpy(adv).float() * lps).sum() / B_PER_GPU
+        loss.backward()
+        opt.step()
+        print(f"[bench] cpu baseline step {s}: {time.perf_counter() - t0:.2f} s", file=sys.stderr, flush=True)
+        if s > 0:
+            times.append(time.perf_counter() - t0)
+    sec = sum(times) / len(times)
+    return {"value": B_PER_GPU / sec, "unit": "utterances/sec", "cores": cores, "kind": "port",
+            "sample": f"{steps} full steps at B={B_PER_GPU},T={T},F={F},V={V} after 1 warm-up; torch-CPU LSTM "
+                      f"(unpacked, lengths=T) + ctc_loss + numpy sampler/greedy/edit distance + Adam; {sec:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from policy_gradient_asr_amd import hipops
+    from policy_gradient_asr_amd.model import Seq2Seq, weights
+    from policy_gradient_asr_amd.train_step import PolicyGradientTrainer
+
+    torch.manual_seed(0)
+    model = Seq2Seq(V, n_feats=F)
+    model.apply(weights)
+    model = model.to(dev).train()
+    model.eval()  # TODO(dropout): train-mode dropout kernels land next; parity mode for now
+    trainer = PolicyGradientTrainer(model, lr=5e-4, lam=1.0, seed=1234, world_size=world)
+    batch = synth_batch(dev, 100 + rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(*batch)
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(f"[bench] warmup step {i} done", file=sys.stderr, flush=True)
+    barrier()
+    hipops.profile_reset(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(*batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(f"[bench] timed region: {dt:.3f} s for {args.steps} steps", file=sys.stderr, flush=True)
+    prof = hipops.profile_collect()
+    hipops.profile_reset(False)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = B_PER_GPU * world * args.steps / dt
+        # dominant kernel: the LSTM sweep with the larger share
+        name, (tot_ms, calls) = max(prof.items(), key=lambda kv: kv[1][0]) if prof else ("none", (0.0, 1))
+        flops_per_launch = 2.0 * 2 * B_PER_GPU * 256 * 1024 * T       # h(B,256) x W_hh^T(256,1024), 2 dirs, T steps
+        avg_ms = tot_ms / max(calls, 1)
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        peak = 157.3
+        out = {
+            "metric": "utterances/sec (B=32,T=1000,F=80) policy-grad step, 1/2/4/8 MI355X",
+            "value": value, "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]+[1]: CTC + REINFORCE train step (greedy baseline, sampled path, WER-style "
+                                   "edit-distance reward), B=32/GPU, T=1000, F=80, V=29, L=100, Adam",
+                       "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}", "dropout": "off (eval mode)"},
+            "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None, "avg_launch_ms": avg_ms,
+                         "launches_per_step": calls / args.steps,
+                         "note": "serial chain of T dependent steps: latency bound, see DESIGN.md"},
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "loss": float(loss.item()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,6 +28,43 @@ def _p(t):
 
 _ws_cache = {}
 
+# ---- optional per-kernel timing with HIP events on the launch stream (used by bench.py) ----
+_prof_on = False
+_prof_events = []
+
+
+def profile_reset(enable):
+    global _prof_on
+    _prof_on = bool(enable)
+    _prof_events.clear()
+
+
+def profile_collect():
+    """name -> (total ms, launches); synchronises."""
+    torch.cuda.synchronize()
+    out = {}
+    for name, e0, e1 in _prof_events:
+        ms, n = out.get(name, (0.0, 0))
+        out[name] = (ms + e0.elapsed_time(e1), n + 1)
+    return out
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _prof_on:
+            self.e0 = torch.cuda.Event(enable_timing=True); self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if _prof_on:
+            self.e1.record()
+            _prof_events.append((self.name, self.e0, self.e1))
+        return False
+
 
 def _workspace(nbytes, device, tag):
     key = (tag, device, torch.cuda.current_stream().cuda_stream)
@@ -138,7 +175,8 @@ def gemm(A, B, C, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=N
     ldc = ldc if ldc is not None else N
     nbytes = lib.pgasr_gemm_workspace_bytes(M, N, batch, splitk, int(sum_batches))
     ws = _workspace(nbytes, C.device, "gemm") if nbytes else None
-    st = lib.pgasr_gemm_f32(int(transA), int(transB), M, N, K, float(alpha),
+    with _timed("gemm_f32"):
+      st = lib.pgasr_gemm_f32(int(transA), int(transB), M, N, K, float(alpha),
                             A.data_ptr() + 4 * a_off, lda, int(strideA), B.data_ptr() + 4 * b_off, ldb, int(strideB),
                             C.data_ptr() + 4 * c_off, ldc, int(strideC), batch, int(sum_batches), splitk,
                             _p(bias), _p(bias2), act, float(slope), int(accumulate), _p(dact_y),
@@ -217,7 +255,8 @@ def _lstm_ws(T, B, backward, device):
 def lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B):
     lib = _lib.load()
     ws = _lstm_ws(T, B, False, gates.device)
-    st = lib.pgasr_lstm_layer_fwd(_p(gates), _p(out), _p(cbuf), _p(pack_f), _p(lengths), T, B, _p(ws), ws.numel(), _stream())
+    with _timed("lstm_fwd_kernel"):
+        st = lib.pgasr_lstm_layer_fwd(_p(gates), _p(out), _p(cbuf), _p(pack_f), _p(lengths), T, B, _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_lstm_layer_fwd")
     return ws
 
@@ -225,8 +264,9 @@ def lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B):
 def lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B):
     lib = _lib.load()
     ws = _lstm_ws(T, B, True, gates.device)
-    st = lib.pgasr_lstm_layer_bwd(_p(gates), _p(out), _p(cbuf), _p(dout), _p(pack_b), _p(lengths), T, B,
-                                  _p(ws), ws.numel(), _stream())
+    with _timed("lstm_bwd_kernel"):
+        st = lib.pgasr_lstm_layer_bwd(_p(gates), _p(out), _p(cbuf), _p(dout), _p(pack_b), _p(lengths), T, B,
+                                      _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_lstm_layer_bwd")
     return ws
 

@@ -1,0 +1,86 @@
+"""Losses of the path.
+
+``customNLLLoss`` keeps the reference's name, constructor and call signature (loss.py:5-17),
+including its quirk that a falsy ignore_index (None or 0) ignores nothing.  ``PGCTCLossFn`` is
+the spec'd objective the reference lacks: CTC + lambda * REINFORCE with a
+self-critical (greedy) baseline, computed by the HIP kernels in one fused gradient pass.
+"""
+import torch
+import torch.nn as nn
+
+from . import hipops
+
+
+class customNLLLoss(nn.Module):
+    """sum_i mean_b( -inp[i, b, target[b, i]] ) for inp (L,B,V) log-probs, target (B,L)."""
+
+    def __init__(self, ignore_index=None):
+        super().__init__()
+        self.ignore_index = ignore_index
+
+    def forward(self, inp, target):
+        L, B, V = inp.shape
+        tgt = target.t().unsqueeze(-1).long()                 # (L,B,1)
+        picked = -inp.gather(2, tgt).squeeze(-1)              # (L,B)
+        if self.ignore_index:                                 # loss.py:9: falsy -> ignore nothing
+            keep = (target.t() != self.ignore_index).to(inp.dtype)
+            return ((picked * keep).sum(dim=1) / keep.sum(dim=1)).sum()
+        return picked.mean(dim=1).sum()
+
+
+class PGCTCLossFn(torch.autograd.Function):
+    """loss = (1/Bg) sum_b [ nll_b / max(L_b,1)  -  lam * (R_s,b - R_g,b) * sum_{t<T_b} log p(pi_t,b) ]
+
+    pi ~ softmax(logits) per frame (Philox, seed-addressable), R = -ED(y, collapse(path)) / max(L,1)
+    for the sampled (R_s) and greedy (R_g, baseline) paths; Bg = global batch (all ranks).
+    Returns (loss, stats) where stats = (nll (B), R_s (B), R_g (B)) detached."""
+
+    @staticmethod
+    def forward(ctx, logits, in_len, targets, tg_len, lam, seed, offset, global_batch, blank):
+        T, B, V = logits.shape
+        dev = logits.device
+        lp = hipops.log_softmax_rows(logits.contiguous())
+        greedy, sample = hipops.frame_argmax_sample(lp, seed=seed, offset=offset)
+        paths = torch.stack((greedy, sample), dim=0).contiguous()            # (2,T,B)
+        tokens, tok_len = hipops.ctc_collapse(paths, in_len, blank=blank)    # (2,B,T), (2,B)
+        ref2 = torch.cat((targets, targets), dim=0).contiguous()
+        rl2 = torch.cat((tg_len, tg_len), dim=0).contiguous()
+        dist = hipops.edit_distance(ref2, rl2, tokens.view(2 * B, T), tok_len.view(2 * B).contiguous())
+        Lf = tg_len.clamp(min=1).to(torch.float32)
+        R_g = -dist[:B].to(torch.float32) / Lf
+        R_s = -dist[B:].to(torch.float32) / Lf
+        inv_bg = 1.0 / float(global_batch)
+        coef = (lam * inv_bg) * (R_s - R_g)
+        utt_scale = inv_bg / Lf
+        nll, grad = hipops.ctc_loss_grad(lp, targets, in_len, tg_len, blank=blank, utt_scale=utt_scale.contiguous(),
+                                         pg_coef=coef.contiguous(), pg_path=sample)
+        tmask = (torch.arange(T, device=dev)[:, None] < in_len[None, :])
+        lps = lp.gather(2, sample.long().unsqueeze(-1)).squeeze(-1) * tmask
+        loss = (nll * utt_scale).sum() - (coef * lps.sum(dim=0)).sum()
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(nll, R_s, R_g)
+        return loss, nll, R_s, R_g
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None, None, None, None, None
+
+
+def pg_ctc_loss(logits, in_len, targets, tg_len, lam=1.0, seed=0, offset=0, global_batch=None, blank=0):
+    B = logits.shape[1]
+    return PGCTCLossFn.apply(logits, in_len, targets, tg_len, float(lam), int(seed), int(offset),
+                             int(global_batch or B), int(blank))
+
+
+class CTCLoss(nn.Module):
+    """CTC-only objective ('mean' reduction: per-utterance nll / max(L,1), mean over the batch)."""
+
+    def __init__(self, blank=0):
+        super().__init__()
+        self.blank = blank
+
+    def forward(self, logits, in_len, targets, tg_len, global_batch=None):
+        loss, _, _, _ = pg_ctc_loss(logits, in_len, targets, tg_len, lam=0.0, global_batch=global_batch,
+                                    blank=self.blank)
+        return loss

@@ -1,0 +1,142 @@
+"""Fused CTC + REINFORCE objective and the full train step against the oracle
+(plumbing config B=4,T=200 of BASELINE.json; tolerance 1e-3 relative)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctc_ref, decode_ref, model_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def oracle_objective(logits, in_len, targets, tg_len, lam, seed, offset, paths=None):
+    """float64 restatement of loss.PGCTCLossFn: returns loss, grad, R_s, R_g, paths."""
+    T, B, V = logits.shape
+    nll, g_ctc = ctc_ref.ctc_loss_and_grad(logits, targets, in_len, tg_len)
+    if paths is None:
+        paths, _, _ = decode_ref.sample_paths(logits, seed=seed, offset=offset)
+    greedy = decode_ref.greedy_decode(logits, in_len)
+    Lf = np.maximum(tg_len, 1).astype(np.float64)
+    R_s = np.zeros(B); R_g = np.zeros(B)
+    for b in range(B):
+        y = list(targets[b][:tg_len[b]])
+        R_s[b] = -decode_ref.edit_dist(y, decode_ref.collapse_path(paths[:in_len[b], b]))[0] / Lf[b]
+        R_g[b] = -decode_ref.edit_dist(y, greedy[b])[0] / Lf[b]
+    coef = lam * (R_s - R_g) / B
+    scale = 1.0 / (Lf * B)
+    lp = ctc_ref.log_softmax(logits, axis=2)
+    mask = np.arange(T)[:, None] < in_len[None, :]
+    lps = (np.take_along_axis(lp, paths[..., None], axis=2)[..., 0] * mask).sum(axis=0)
+    loss = (nll * scale).sum() - (coef * lps).sum()
+    grad = g_ctc * scale[None, :, None] + decode_ref.reinforce_grad(logits, paths, coef, in_len)
+    return loss, grad, R_s, R_g, paths
+
+
+@pytest.mark.parametrize("lam", [0.0, 1.0])
+def test_pg_ctc_loss_vs_oracle(lam):
+    from policy_gradient_asr_amd.loss import pg_ctc_loss
+    T, B, V, L = 200, 4, 29, 20
+    g = torch.Generator().manual_seed(11)
+    logits = torch.randn(T, B, V, generator=g) * 2
+    logits[:, :, 0] += 2.0
+    targets = torch.randint(1, V, (B, L), generator=g, dtype=torch.int32)
+    in_len = torch.tensor([200, 150, 200, 99], dtype=torch.int32)
+    tg_len = torch.tensor([20, 12, 20, 7], dtype=torch.int32)
+    lg = logits.to(DEV).requires_grad_(True)
+    loss, nll, R_s, R_g = pg_ctc_loss(lg, in_len.to(DEV), targets.to(DEV), tg_len.to(DEV), lam=lam, seed=77, offset=5)
+    loss.backward()
+    want_loss, want_grad, wRs, wRg, _ = oracle_objective(logits.double().numpy(), in_len.numpy(), targets.numpy(),
+                                                         tg_len.numpy(), lam, 77, 5)
+    np.testing.assert_allclose(R_g.cpu().numpy(), wRg, rtol=1e-6)
+    np.testing.assert_allclose(R_s.cpu().numpy(), wRs, rtol=1e-6)
+    assert abs(float(loss) - want_loss) / abs(want_loss) < 1e-4
+    assert rel_err(lg.grad.cpu(), want_grad) < 1e-3
+
+
+def _make(B, F, T, V, L, lens, tlens, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, F, T, generator=g)
+    fmask = torch.zeros(B, T)
+    for b, n in enumerate(lens):
+        fmask[b, :n] = 1; x[b, :, n:] = 0
+    targets = torch.randint(1, V, (B, L), generator=g)
+    tmask = torch.zeros(B, L, dtype=torch.int64)
+    for b, n in enumerate(tlens):
+        tmask[b, :n] = 1; targets[b, n:] = 0
+    return x, targets, fmask, tmask
+
+
+def test_ctc_train_step_grads_vs_oracle_plumbing_config():
+    """configs[0]: B=4,T=200,F=80,V=29 CTC-only step: loss and every parameter gradient."""
+    from policy_gradient_asr_amd.model import Seq2Seq
+    from policy_gradient_asr_amd.loss import pg_ctc_loss
+    B, F, T, V, L = 4, 80, 200, 29, 20
+    lens, tlens = [200, 170, 200, 120], [20, 15, 20, 9]
+    x, targets, fmask, tmask = _make(B, F, T, V, L, lens, tlens, 5)
+    p = model_ref.init_params(n_feats=F, vocab=V, seed=2)
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    enc = model_ref.encoder_forward_torch(pr, x, fmask)
+    lp = model_ref.head_forward_torch(pr, enc)
+    ref = torch.nn.functional.ctc_loss(lp, targets, torch.tensor(lens), torch.tensor(tlens), blank=0, reduction="mean")
+    ref.backward()
+    m = Seq2Seq(V, n_feats=F)
+    m.load_state_dict({("encoder." + k if not k.startswith("head.") else k): v for k, v in p.items()}, strict=True)
+    m = m.to(DEV).eval()
+    logits, in_len = m.logits(x.to(DEV), fmask.to(DEV))
+    loss, nll, _, _ = pg_ctc_loss(logits, in_len, targets.to(torch.int32).to(DEV),
+                                  torch.tensor(tlens, dtype=torch.int32, device=DEV), lam=0.0)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) / abs(float(ref)) < 1e-3
+    for k, v in m.named_parameters():
+        rk = k[len("encoder."):] if k.startswith("encoder.") else k
+        assert rel_err(v.grad.cpu(), pr[rk].grad) < 1e-3, k
+
+
+def test_pg_train_step_grads_vs_oracle_with_shared_paths():
+    """lam=1: the discrete choices (sampled + greedy paths) must agree with the oracle's on the
+    oracle's own logits; gradients then agree to 1e-3."""
+    from policy_gradient_asr_amd.model import Seq2Seq
+    from policy_gradient_asr_amd.loss import pg_ctc_loss
+    B, F, T, V, L = 4, 80, 120, 29, 12
+    lens, tlens = [120, 90, 120, 64], [12, 9, 12, 5]
+    x, targets, fmask, tmask = _make(B, F, T, V, L, lens, tlens, 9)
+    p = model_ref.init_params(n_feats=F, vocab=V, seed=4)
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    enc = model_ref.encoder_forward_torch(pr, x, fmask)
+    logits_ref = model_ref.head_logits_torch(pr, enc)
+    m = Seq2Seq(V, n_feats=F)
+    m.load_state_dict({("encoder." + k if not k.startswith("head.") else k): v for k, v in p.items()}, strict=True)
+    m = m.to(DEV).eval()
+    logits, in_len = m.logits(x.to(DEV), fmask.to(DEV))
+    loss, nll, R_s, R_g = pg_ctc_loss(logits, in_len, targets.to(torch.int32).to(DEV),
+                                      torch.tensor(tlens, dtype=torch.int32, device=DEV), lam=1.0, seed=3, offset=1)
+    loss.backward()
+    w_loss, w_grad, wRs, wRg, _ = oracle_objective(logits_ref.detach().double().numpy(), np.array(lens), targets.numpy(),
+                                                   np.array(tlens), 1.0, 3, 1)
+    np.testing.assert_allclose(R_g.cpu().numpy(), wRg, rtol=1e-6)
+    np.testing.assert_allclose(R_s.cpu().numpy(), wRs, rtol=1e-6)
+    assert abs(float(loss) - w_loss) / abs(w_loss) < 1e-3
+    logits_ref.backward(torch.from_numpy(w_grad).float())
+    for k, v in m.named_parameters():
+        rk = k[len("encoder."):] if k.startswith("encoder.") else k
+        assert rel_err(v.grad.cpu(), pr[rk].grad) < 1e-3, k
+
+
+def test_trainer_steps_reduce_loss():
+    from policy_gradient_asr_amd.model import Seq2Seq, weights
+    from policy_gradient_asr_amd.train_step import PolicyGradientTrainer
+    torch.manual_seed(0)
+    B, F, T, V, L = 4, 80, 100, 29, 10
+    x, targets, fmask, tmask = _make(B, F, T, V, L, [100] * 4, [10] * 4, 1)
+    m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(DEV).eval()
+    tr = PolicyGradientTrainer(m, lr=2e-3, lam=0.0, seed=1)   # CTC-only: the loss value is monotone-ish
+    losses = [float(tr.step(x.to(DEV), targets.to(DEV), fmask.to(DEV), tmask.to(DEV))) for _ in range(12)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    # parameters are views of the flat buffer
+    assert m.head.weight.data_ptr() >= tr.flat.data_ptr()
