@@ -160,8 +160,10 @@ int pgasr_log_softmax_rows(const float* logits, long long rows, int V, float* lo
  *   the caller forms dX = dgates * wih_perm, dW_ih = dgates^T X, dW_hh = dgates^T h_prev with
  *   pgasr_gemm_f32 and maps them back with pgasr_lstm_unpack_grads.
  * The sweeps are persistent kernels: 16 workgroups per (direction, 16-utterance group) that hand
- * h_t / dgates_t to each other through HBM every step (write-through stores + one counter).
- * Limit: B <= 128.  workspace (pgasr_lstm_workspace_bytes) holds exchange buffers, counters and an
+ * h_t / partial dh sums to each other through global memory every step (self-validating words; plain
+ * stores when the cluster is verified to share an XCD, write-through stores otherwise).
+ * flags bit 0: force the write-through protocol (testing the placement-independent path).
+ * Limit: B <= 128.  workspace (pgasr_lstm_workspace_bytes) holds exchange buffers and an
  * error word (offset: pgasr_lstm_error_offset) that is set when a bounded wait times out.
  * ---------------------------------------------------------------------------------------- */
 size_t pgasr_lstm_pack_bytes(int which);
@@ -176,10 +178,10 @@ int pgasr_lstm_unpack_grads(const float* dwih_perm, const float* dbias_perm, con
 size_t pgasr_lstm_workspace_bytes(int T, int B, int backward);
 int pgasr_lstm_error_offset(int B, int backward, size_t* offset);
 int pgasr_lstm_layer_fwd(float* gates, float* out, float* cbuf, const void* whh_pack_fwd,
-                         const int32_t* lengths, int T, int B,
+                         const int32_t* lengths, int T, int B, int flags,
                          void* workspace, size_t workspace_bytes, void* stream);
 int pgasr_lstm_layer_bwd(float* gates, const float* out, const float* cbuf, const float* dout,
-                         const void* whh_pack_bwd, const int32_t* lengths, int T, int B,
+                         const void* whh_pack_bwd, const int32_t* lengths, int T, int B, int flags,
                          void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpgasr_hip.so")
+LIB_PATH = os.environ.get("PGASR_HIP_LIB", os.path.join(_HERE, "libpgasr_hip.so"))   # override: diagnostic builds
 
 c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 c_i32p = C.c_void_p
@@ -43,9 +43,9 @@ SIGNATURES = {
     "pgasr_lstm_unpack_grads": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int] + [c_f32p] * 8 + [C.c_int, c_ptr]),
     "pgasr_lstm_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "pgasr_lstm_error_offset": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
-    "pgasr_lstm_layer_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int,
+    "pgasr_lstm_layer_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int,
                                        c_ptr, C.c_size_t, c_ptr]),
-    "pgasr_lstm_layer_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int,
+    "pgasr_lstm_layer_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int,
                                        c_ptr, C.c_size_t, c_ptr]),
 }
 

@@ -6,25 +6,18 @@
 //
 // Design (DESIGN.md "LSTM recurrence"): W_hh (1 MB fp32) does not fit one CU, so each
 // (direction, 16-utterance batch group) is served by a CLUSTER of 16 persistent workgroups, one
-// per CU, each owning 16 hidden units.  The weight slice stays in registers for the whole sweep
-// (64 VGPRs of bf16 hi/lo pairs per lane); every step a workgroup
-//   1. waits until the 16 slices of h_{t-1} are published (one monotonic counter per cluster),
-//   2. loads h_{t-1} (16 utt x 256, as bf16 hi+lo = 16 KB) straight into MFMA B-operand registers,
-//   3. 24 x v_mfma_f32_16x16x32_bf16 per wave: hi*hi + hi*lo + lo*hi with fp32 accumulation
-//      (the 3-term split keeps ~16 mantissa bits per operand: error ~1e-5 of a gate pre-activation,
-//      against 2e-3 for plain bf16),
-//   4. gate math in fp32, state c/h in registers,
-//   5. publishes its 16 x 16 slice of h_t: bf16 hi/lo re-laid out through LDS into the consumers'
-//      operand order and written with ONE 1-KiB write-through (sc1) store, drained, then one
-//      agent-scope atomic add on the cluster counter.
-// Hand-off protocol = MI355X_MICROARCH.md "Valid forms", table row 1: every payload store sc1 and
-// drained (s_waitcnt vmcnt(0)) by the storing wave before one lane signals; consumers poll the
-// counter with sc1 loads, join a workgroup barrier, and read the payload ONLY with sc1 loads.
-// No result depends on dispatch order or XCD placement; every spin is bounded (err flag + exit).
-//
-// The backward sweep has the same skeleton with K = 1024 (all gate gradients of the cluster) split
-// over the 4 waves and reduced through LDS; it overwrites the saved gate activations with dgates
-// in place, which the weight-gradient GEMMs then consume.
+// per CU, each owning 16 hidden units, with its weight slice resident in registers (64 VGPRs of
+// bf16 hi/lo pairs per lane) for the whole sweep.  Matrix products run on
+// v_mfma_f32_16x16x32_bf16 as hi*hi + hi*lo + lo*hi with fp32 accumulation (~15-16 mantissa bits
+// per operand; measured 1e-5 relative on layer outputs against fp64).  Per step the members
+// exchange h_t (forward, 16 KiB) or partial dh sums (backward, 16 KiB read per member) through
+// global memory using self-validating words (below): no flag, counter, fence or drain sits on
+// the dependent chain, results cannot depend on dispatch order, XCD placement or the order in
+// which stores become visible, and every spin is bounded (err word + exit).
+// Placement is used for SPEED only: the grid is laid out so that a cluster's members share
+// blockIdx % 8 (one XCD under the observed round-robin dispatch); the members check at run time
+// (HW_REG_XCC_ID) whether they really share an XCD and then publish with plain stores that stay
+// in that XCD's L2, otherwise with write-through (sc1) stores.  Loads always bypass L1 (sc1).
 #include "common.h"
 
 namespace {
@@ -32,6 +25,7 @@ namespace {
 constexpr int HID = 256;           // hidden size per direction (model.py:40)
 constexpr int G_CLUSTER = 16;      // workgroups per (direction, batch group): 16 units each
 constexpr int LSTM_THREADS = 256;
+constexpr int STAMP_MAX_T = 4096;
 constexpr long long SPIN_TIMEOUT_TICKS = 300000000LL;  // 3 s of the 100 MHz realtime counter
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -58,312 +52,391 @@ struct LstmArgs {
     float* cbuf;             // [T][B][2][H] c_t
     const float* dout;       // [T][B][2H]   (backward) gradient w.r.t. out
     const u32x4* wpack;      // packed bf16 hi/lo W_hh in MFMA A-operand order (see pack kernel)
-    unsigned char* xbuf;     // exchange buffers
-    unsigned* ctr;           // [2][NBG] counters, 32 words apart
+    unsigned char* xbuf;     // exchange buffers, pre-filled with the "stale" pattern
+    unsigned* hello;         // [clusters][16] start-up words (XCC id of each member), zeroed per call
     int* err;                // set to 1 when a bounded wait gives up
     const int* lengths;      // [B]
-    int T, B, NBG;
+    int T, B, NBG, NCL8;
+    int force_mode;          // 0 auto, 1 force write-through (cross-XCD safe), for tests
+    long long* stamps;       // diagnostic build only (-DPGASR_LSTM_STAMPS)
 };
 
-// bounded wait of wave 0 on the cluster counter; returns false on timeout
-__device__ __forceinline__ bool wait_counter(unsigned* ctr, unsigned target) {
-    unsigned v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (v >= target) return true;
-    const long long t0 = wall_clock64();
-    unsigned spins = 0;
-    while (true) {
-        __builtin_amdgcn_s_sleep(1);
-        v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v >= target) return true;
+#ifdef PGASR_LSTM_STAMPS
+#define STAMP(slot) do { if (g == 5 && bg == 0 && dir == 0 && tid == 0) a.stamps[(size_t)step * 8 + (slot)] = clock64(); } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
+// ---- self-validating exchange words -------------------------------------------------------
+// Every 32-bit word of an exchange buffer carries the epoch of the step that produced it in
+// bits that are numerically harmless: e = (step>>1)&1 and
+//   * bf16-pair words (forward h):  (bit0, bit16) = (e, 1-e)   -- the mantissa LSBs of the pair;
+//   * fp32 words (backward partial sums): (bit0, bit1) = (e, 1-e).
+// A slot (step&1) is rewritten every second step, so a word still holding the previous round
+// shows the complementary pattern: the bit that must be 0 in fresh data is 1.  A consumer ORs
+// the words it loaded and tests that one bit -- no flag, counter, fence or drain sits on the
+// dependent chain and no ordering between stores is assumed: each aligned dword is written
+// atomically and validates itself (the guide's R2 "the data IS the flag", at word granularity).
+// For bf16 pairs the hi part is rounded with its LSB forced and the lo part is the residual to
+// THAT value, so hi+lo still carries ~15 mantissa bits and the tag never needs masking.
+__device__ __forceinline__ void split_tagged(float x, unsigned tb, unsigned short& hi, unsigned short& lo) {
+    const unsigned short h = (unsigned short)((f2bf(x) & 0xFFFEu) | tb);
+    const unsigned short l = (unsigned short)((f2bf(x - bf2f(h)) & 0xFFFEu) | tb);
+    hi = h; lo = l;
+}
+__device__ __forceinline__ void split_plain(float x, unsigned short& hi, unsigned short& lo) {
+    hi = f2bf(x);
+    lo = f2bf(x - bf2f(hi));
+}
+__device__ __forceinline__ unsigned or4(u32x4 v) { return (v.x | v.y) | (v.z | v.w); }
+
+struct SpinGuard {
+    unsigned spins = 0; long long t0 = 0;
+    // returns false when the wait has lasted longer than SPIN_TIMEOUT_TICKS
+    __device__ __forceinline__ bool keep_waiting() {
+        if (spins == 0) t0 = wall_clock64();
         if (((++spins) & 1023u) == 0 && wall_clock64() - t0 > SPIN_TIMEOUT_TICKS) return false;
+        return true;
     }
+};
+
+// Cluster start-up: every member publishes the XCD it runs on (HW_REG_XCC_ID); all members read
+// the same 16 words, so they reach the same verdict.  true = the whole cluster shares one XCD
+// (one L2): payload stores may stay in that L2 (plain stores), which consumers reach with
+// L1-bypassing loads at L2-hit latency.  Otherwise stores are write-through (sc1) so that they
+// reach memory where any XCD sees them.  Placement only selects the faster legal protocol.
+__device__ __forceinline__ bool cluster_same_xcd(const LstmArgs& a, int cl, int g, int tid, volatile int* s_flag,
+                                                 volatile int* s_abort) {
+    if (tid < 64) {
+        unsigned* hw = a.hello + (size_t)cl * 16;
+        const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xFu;
+        if (tid == 0) __hip_atomic_store(hw + g, 0x100u | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SpinGuard sg;
+        unsigned v = 0x100u | xcc;
+        while (true) {
+            if (tid < 16) v = __hip_atomic_load(hw + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!__any(v == 0u)) break;
+            if (!sg.keep_waiting()) { *s_abort = 1; *a.err = 1; break; }
+        }
+        const bool same = !__any((v & 0xFu) != xcc);
+        if (tid == 0) *s_flag = (same && a.force_mode == 0) ? 1 : 0;
+    }
+    __syncthreads();
+    return *s_flag != 0;
 }
 
 // ------------------------------------------------------------------------------------------
-// forward sweep.  grid (16, NBG, 2); wave w of workgroup g owns units 4*(4g+w) .. +3
+// forward sweep.  1-D grid of 16*NCL8 workgroups: cluster cl = b % NCL8 (members share b % 8,
+// i.e. an XCD under the observed round-robin placement), member g = b / NCL8 owns hidden units
+// 16g..16g+15.  Wave w multiplies the k-quarter [64w, 64w+64) of h_{t-1} into all 64 gate rows
+// of the workgroup (4 MFMA tiles x 2 k-steps x 3 split terms); the four partial tiles are
+// summed through LDS and each thread finishes ONE (unit, utterance) cell.
+// exchange slot per cluster: [parity 2][kc 32][n 16][hl 2][8 bf16]; producer g owns
+// kc = 2g, 2g+1 = one contiguous 1-KiB block written by ONE wave-instruction.
 // ------------------------------------------------------------------------------------------
-template <int NT>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
-    const int g = blockIdx.x, bg = blockIdx.y, dir = blockIdx.z;
+    const int cl = blockIdx.x % a.NCL8, g = blockIdx.x / a.NCL8;
+    if (cl >= 2 * a.NBG) return;
+    const int dir = cl & 1, bg = cl >> 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int q = lane >> 4, n = lane & 15;
-    const int tau = 4 * g + w;
-    const int unit = 4 * tau + q;
+    const int q = lane >> 4, n = lane & 15;      // MFMA coordinates
+    const int pu = tid & 15, pn = tid >> 4;      // cell coordinates (unit fastest: coalesced stores)
+    const int unit = 16 * g + pu;
     const int T = a.T, B = a.B;
 
-    __shared__ __attribute__((aligned(16))) unsigned short hs[NT * 16 * 2 * 16];  // [nt][n][hl][16 units]
+    constexpr int PROW = 16 * 4 + 4;             // padded row of 16 units x 4 gates (conflict-free both ways)
+    __shared__ __attribute__((aligned(16))) float part[4 * 16 * PROW];          // [w][n][u][gate]
+    __shared__ __attribute__((aligned(16))) unsigned short hs[2 * 16 * 2 * 8];  // [c2][n][hl][8 units]
     __shared__ volatile int s_abort;
-    if (tid == 0) s_abort = 0;
+    __shared__ volatile int s_same;
+    if (tid == 0) { s_abort = 0; s_same = 0; }
+    __syncthreads();
 
-    // weight slice -> registers (A operand: row = 4*uu+gate, k = 32ks + 8(l>>4) + j)
-    bf16x8 Whi[8], Wlo[8];
-    {
-        const u32x4* wp = a.wpack + ((size_t)(dir * 64 + tau) * 8) * 2 * 64;
+    // weight slices -> registers: tile m (units 4(4g+m)..+3, row = 4*uu+gate), k-steps 2w, 2w+1
+    bf16x8 Whi[4][2], Wlo[4][2];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            Whi[ks] = __builtin_bit_cast(bf16x8, wp[(ks * 2 + 0) * 64 + lane]);
-            Wlo[ks] = __builtin_bit_cast(bf16x8, wp[(ks * 2 + 1) * 64 + lane]);
+    for (int m = 0; m < 4; ++m) {
+        const u32x4* wp = a.wpack + ((size_t)(dir * 64 + 4 * g + m) * 8) * 2 * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            Whi[m][i] = __builtin_bit_cast(bf16x8, wp[((2 * w + i) * 2 + 0) * 64 + lane]);
+            Wlo[m][i] = __builtin_bit_cast(bf16x8, wp[((2 * w + i) * 2 + 1) * 64 + lane]);
         }
     }
-    const size_t xregion = (size_t)2 * NT * 32 * 16 * 2 * 16;  // bytes per (dir,bg): [parity][nt][kc][n][hl][16B]
-    unsigned char* xb = a.xbuf + (size_t)(dir * a.NBG + bg) * xregion;
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)xregion, 0x00020000);
-    unsigned* ctr = a.ctr + (size_t)(dir * a.NBG + bg) * 32;
+    constexpr unsigned SLOT = 32 * 16 * 2 * 16;       // bytes per parity slot (16 KiB)
+    unsigned char* xb = a.xbuf + (size_t)cl * (2 * SLOT);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)(2 * SLOT), 0x00020000);
+    const bool same_xcd = cluster_same_xcd(a, cl, g, tid, &s_same, &s_abort);
 
-    int bidx[NT], len[NT];
-    float c[NT], h[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        bidx[nt] = bg * 16 * NT + nt * 16 + n;
-        len[nt] = (bidx[nt] < B) ? a.lengths[bidx[nt]] : 0;
-        c[nt] = 0.f; h[nt] = 0.f;
-    }
-    auto gate_ptr = [&](int t, int nt) {
-        return reinterpret_cast<float4*>(a.gates + ((((size_t)t * B + bidx[nt]) * 2 + dir) * HID + unit) * 4);
+    const int bidx = bg * 16 + pn;
+    const int len = (bidx < B) ? a.lengths[bidx] : 0;
+    float c = 0.f, h = 0.f;
+    auto gate_ptr = [&](int t) {
+        return reinterpret_cast<float4*>(a.gates + ((((size_t)t * B + bidx) * 2 + dir) * HID + unit) * 4);
     };
-    float4 xg[NT];
-    {
-        const int t = dir ? T - 1 : 0;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) xg[nt] = (bidx[nt] < B) ? *gate_ptr(t, nt) : make_float4(0, 0, 0, 0);
-    }
-    __syncthreads();
+    float4 xg = (bidx < B) ? *gate_ptr(dir ? T - 1 : 0) : make_float4(0, 0, 0, 0);
+    // results of the previous step, stored one step late so that their (scattered) stores are
+    // issued behind the next step's operand loads instead of in front of them
+    float4 def_g = make_float4(0, 0, 0, 0); float def_c = 0.f, def_h = 0.f; int def_t = -1;
+    auto flush_deferred = [&]() {
+        if (def_t >= 0 && bidx < B) {
+            *gate_ptr(def_t) = def_g;
+            a.cbuf[(((size_t)def_t * B + bidx) * 2 + dir) * HID + unit] = def_c;
+            a.out[((size_t)def_t * B + bidx) * (2 * HID) + dir * HID + unit] = def_h;
+        }
+        def_t = -1;
+    };
 
     for (int step = 0; step < T; ++step) {
         const int t = dir ? T - 1 - step : step;
-        float4 xn[NT];
-        if (step + 1 < T) {
-            const int tn = dir ? t - 1 : t + 1;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) xn[nt] = (bidx[nt] < B) ? *gate_ptr(tn, nt) : make_float4(0, 0, 0, 0);
-        }
-        f32x4 acc[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
+        float4 xn = make_float4(0, 0, 0, 0);
+        if (step + 1 < T && bidx < B) xn = *gate_ptr(dir ? t - 1 : t + 1);
+        float4 pre = xg;
+        STAMP(0);
         if (step > 0) {
-            if (w == 0) {
-                if (!wait_counter(ctr, (unsigned)(G_CLUSTER * step))) { s_abort = 1; *a.err = 1; }
+            const unsigned pbase = (unsigned)((step - 1) & 1) * SLOT;
+            const unsigned stale_bit = (((step - 1) >> 1) & 1) ? 0x00010000u : 0x00000001u;
+            bf16x8 Hhi[2], Hlo[2];
+            u32x4 vh[2], vl[2];
+            auto issue_loads = [&]() {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned off = pbase + (unsigned)((((4 * (2 * w + i) + q) * 16 + n) * 2) * 16);
+                    vh[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
+                    vl[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 16);
+                }
+            };
+            issue_loads();            // the operand loads ARE the poll
+            flush_deferred();         // previous step's bulk stores ride behind them
+            SpinGuard sg;
+            while (true) {
+                const unsigned orr = (or4(vh[0]) | or4(vl[0])) | (or4(vh[1]) | or4(vl[1]));
+                if (!__any((orr & stale_bit) != 0)) break;
+                if (s_abort || !sg.keep_waiting()) { s_abort = 1; *a.err = 1; break; }
+                issue_loads();
             }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                Hhi[i] = __builtin_bit_cast(bf16x8, vh[i]);
+                Hlo[i] = __builtin_bit_cast(bf16x8, vl[i]);
+            }
+            STAMP(1);
+            f32x4 acc[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[m][i], Hhi[i], acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[m][i], Hlo[i], acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wlo[m][i], Hhi[i], acc[m], 0, 0, 0);
+            }
+            // tile m, lane (q,n): gates of local unit 4m+q for utterance n
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                *reinterpret_cast<float4*>(&part[(w * 16 + n) * PROW + (4 * m + q) * 4]) =
+                    make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+            STAMP(2);
             __syncthreads();
-            if (s_abort) break;
-            const int p = (step - 1) & 1;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                bf16x8 Hhi[8], Hlo[8];
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    const unsigned off = (unsigned)(((((p * NT + nt) * 32 + (4 * ks + q)) * 16 + n) * 2) * 16);
-                    Hhi[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16));
-                    Hlo[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 16));
-                }
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[ks], Hhi[ks], acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[ks], Hlo[ks], acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wlo[ks], Hhi[ks], acc[nt], 0, 0, 0);
-                }
-            }
+            STAMP(3);
+            const float* pp = &part[pn * PROW + pu * 4];
+            const float4 p0 = *reinterpret_cast<const float4*>(pp);
+            const float4 p1 = *reinterpret_cast<const float4*>(pp + 16 * PROW);
+            const float4 p2 = *reinterpret_cast<const float4*>(pp + 32 * PROW);
+            const float4 p3 = *reinterpret_cast<const float4*>(pp + 48 * PROW);
+            pre.x += (p0.x + p1.x) + (p2.x + p3.x);
+            pre.y += (p0.y + p1.y) + (p2.y + p3.y);
+            pre.z += (p0.z + p1.z) + (p2.z + p3.z);
+            pre.w += (p0.w + p1.w) + (p2.w + p3.w);
         }
-        float4 gsave[NT];
-        float hout[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float gi = sigmoidf_fast(acc[nt][0] + xg[nt].x);
-            const float gf = sigmoidf_fast(acc[nt][1] + xg[nt].y);
-            const float gg = tanhf_fast(acc[nt][2] + xg[nt].z);
-            const float go = sigmoidf_fast(acc[nt][3] + xg[nt].w);
-            const bool active = t < len[nt];
-            const float cn = gf * c[nt] + gi * gg;
-            const float hn = go * tanhf_fast(cn);
-            if (active) { c[nt] = cn; h[nt] = hn; }
-            gsave[nt] = active ? make_float4(gi, gf, gg, go) : make_float4(0, 0, 0, 0);
-            hout[nt] = active ? hn : 0.f;
+        const float gi = sigmoidf_fast(pre.x);
+        const float gf = sigmoidf_fast(pre.y);
+        const float gg = tanhf_fast(pre.z);
+        const float go = sigmoidf_fast(pre.w);
+        const bool active = t < len;
+        const float cn = gf * c + gi * gg;
+        const float hn = go * tanhf_fast(cn);
+        if (active) { c = cn; h = hn; }
+        {
+            const unsigned e = (unsigned)(step >> 1) & 1u;
+            const unsigned tb = (pu & 1) ? (1u - e) : e;
             unsigned short hi, lo;
-            split_bf16(h[nt], hi, lo);
-            hs[((nt * 16 + n) * 2 + 0) * 16 + 4 * w + q] = hi;
-            hs[((nt * 16 + n) * 2 + 1) * 16 + 4 * w + q] = lo;
+            split_tagged(h, tb, hi, lo);
+            hs[(((pu >> 3) * 16 + pn) * 2 + 0) * 8 + (pu & 7)] = hi;
+            hs[(((pu >> 3) * 16 + pn) * 2 + 1) * 8 + (pu & 7)] = lo;
         }
+        STAMP(4);
         __syncthreads();
+        STAMP(5);
+        if (s_abort) break;
         if (w == 0 && step + 1 < T) {
-            const int p = step & 1;
-            const int ln = lane >> 2, lhl = (lane >> 1) & 1, lc2 = lane & 1;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(&hs[(nt * 64 + lane) * 8]);
-                const unsigned off = (unsigned)((((((p * NT + nt) * 32 + (2 * g + lc2)) * 16 + ln) * 2) + lhl) * 16);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 16);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(&hs[lane * 8]);
+            const unsigned off = (unsigned)(step & 1) * SLOT + (unsigned)g * 1024u + (unsigned)lane * 16u;
+            if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 0);    // stays in the shared L2
+            else          __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 16);   // write-through (sc1)
         }
-        // bulk stores for the backward pass / next layer (off the dependent chain)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            if (bidx[nt] < B) {
-                *gate_ptr(t, nt) = gsave[nt];
-                a.cbuf[(((size_t)t * B + bidx[nt]) * 2 + dir) * HID + unit] = c[nt];
-                a.out[((size_t)t * B + bidx[nt]) * (2 * HID) + dir * HID + unit] = hout[nt];
-            }
-            xg[nt] = xn[nt];
-        }
+        // results for the backward pass / next layer: stored at the top of the next step
+        def_g = active ? make_float4(gi, gf, gg, go) : make_float4(0, 0, 0, 0);
+        def_c = c; def_h = active ? hn : 0.f; def_t = t;
+        STAMP(6);
+        xg = xn;
     }
+    flush_deferred();
 }
 
 // ------------------------------------------------------------------------------------------
-// backward sweep.  grid (16, NBG, 2); workgroup g owns OUTPUT units 16g..16g+15 of
-// dh_{prev} = dgates * W_hh; wave w reduces over gate rows r' in [256w, 256w+256).
+// backward sweep.  Same grid and ownership (member g owns units 16g..16g+15).  The recurrent
+// gradient dh_{prev}[k] = sum_r dgates[r] W_hh[r,k] is formed as a sum of 16 PARTIAL products,
+// one per member, each over the member's own 64 gate rows (K = 64): every step a workgroup
+//   1. loads the 16 partial sums addressed to its units (16 fp32 words per thread, tagged),
+//   2. finishes one (unit, utterance) cell: dgates from the saved activations,
+//   3. multiplies its dgates (bf16 hi/lo through LDS) into all 256 outputs
+//      (16 MFMA tiles over the 4 waves, 2 k-steps x 3 split terms) and
+//   4. publishes that partial: [src g][n 16][unit 256] fp32 = 16 KiB, 4 x 16-B stores per lane.
+// Exchange read per workgroup and step: 16 KiB (a dgates all-gather would be 64 KiB).
 // ------------------------------------------------------------------------------------------
-template <int NT>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
-    const int g = blockIdx.x, bg = blockIdx.y, dir = blockIdx.z;
+    const int cl = blockIdx.x % a.NCL8, g = blockIdx.x / a.NCL8;
+    if (cl >= 2 * a.NBG) return;
+    const int dir = cl & 1, bg = cl >> 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int q = lane >> 4, n = lane & 15;   // MFMA operand coordinates
-    const int ul = tid >> 4, pn = tid & 15;   // pointwise coordinates: local unit, batch column
-    const int unit = 16 * g + ul;
+    const int q = lane >> 4, n = lane & 15;      // MFMA coordinates
+    const int pu = tid & 15, pn = tid >> 4;      // cell coordinates (unit fastest: coalesced partial reads)
+    const int unit = 16 * g + pu;
     const int T = a.T, B = a.B;
 
-    __shared__ __attribute__((aligned(16))) float part[NT * 4 * 16 * 16];              // [nt][w][m][n]
-    __shared__ __attribute__((aligned(16))) unsigned short dgs[NT * 16 * 2 * 64];      // [nt][n][hl][64 r']
+    __shared__ __attribute__((aligned(16))) unsigned short dgl[2 * 16 * 2 * 64];   // [buf][n][hl][64 r' local]
     __shared__ volatile int s_abort;
-    if (tid == 0) s_abort = 0;
+    __shared__ volatile int s_same;
+    if (tid == 0) { s_abort = 0; s_same = 0; }
+    __syncthreads();
 
-    bf16x8 Whi[8], Wlo[8];
-    {
-        const u32x4* wp = a.wpack + ((size_t)(dir * 16 + g) * 32) * 2 * 64;
+    // A operand tiles: output units 16*(4w+mt)..+15 (rows), k = own gate rows r' = 64g + 32i + ..
+    bf16x8 Whi[4][2], Wlo[4][2];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int ks = 8 * w + i;
-            Whi[i] = __builtin_bit_cast(bf16x8, wp[(ks * 2 + 0) * 64 + lane]);
-            Wlo[i] = __builtin_bit_cast(bf16x8, wp[(ks * 2 + 1) * 64 + lane]);
+    for (int mt = 0; mt < 4; ++mt) {
+        const u32x4* wp = a.wpack + ((size_t)(dir * 16 + 4 * w + mt) * 32) * 2 * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            Whi[mt][i] = __builtin_bit_cast(bf16x8, wp[((2 * g + i) * 2 + 0) * 64 + lane]);
+            Wlo[mt][i] = __builtin_bit_cast(bf16x8, wp[((2 * g + i) * 2 + 1) * 64 + lane]);
         }
     }
-    const size_t xregion = (size_t)2 * NT * 128 * 16 * 2 * 16;  // [parity][nt][kc 128][n][hl][16B]
-    unsigned char* xb = a.xbuf + (size_t)(dir * a.NBG + bg) * xregion;
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)xregion, 0x00020000);
-    unsigned* ctr = a.ctr + (size_t)(dir * a.NBG + bg) * 32;
+    constexpr unsigned SLOT = 16 * 16 * 256 * 4;      // [src 16][n 16][unit 256] fp32 = 256 KiB
+    unsigned char* xb = a.xbuf + (size_t)cl * (2 * SLOT);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)(2 * SLOT), 0x00020000);
+    const bool same_xcd = cluster_same_xcd(a, cl, g, tid, &s_same, &s_abort);
 
-    int bidx[NT], len[NT];
-    float dc[NT], carry[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        bidx[nt] = bg * 16 * NT + nt * 16 + pn;
-        len[nt] = (bidx[nt] < B) ? a.lengths[bidx[nt]] : 0;
-        dc[nt] = 0.f; carry[nt] = 0.f;
-    }
+    const int bidx = bg * 16 + pn;
+    const int len = (bidx < B) ? a.lengths[bidx] : 0;
+    float dc = 0.f, carry = 0.f;
     struct Saved { float4 gt; float ct, cp, dy; };
-    auto load_saved = [&](int t, int nt) {
+    auto load_saved = [&](int t) {
         Saved s; s.gt = make_float4(0, 0, 0, 0); s.ct = 0.f; s.cp = 0.f; s.dy = 0.f;
-        if (bidx[nt] < B) {
-            const size_t gi = (((size_t)t * B + bidx[nt]) * 2 + dir) * HID + unit;
+        if (bidx < B) {
+            const size_t gi = (((size_t)t * B + bidx) * 2 + dir) * HID + unit;
             s.gt = *reinterpret_cast<const float4*>(a.gates + gi * 4);
             s.ct = a.cbuf[gi];
             const int tp = dir ? t + 1 : t - 1;   // the step the forward sweep ran just before t
-            if (tp >= 0 && tp < T) s.cp = a.cbuf[(((size_t)tp * B + bidx[nt]) * 2 + dir) * HID + unit];
-            s.dy = a.dout[((size_t)t * B + bidx[nt]) * (2 * HID) + dir * HID + unit];
+            if (tp >= 0 && tp < T) s.cp = a.cbuf[(((size_t)tp * B + bidx) * 2 + dir) * HID + unit];
+            s.dy = a.dout[((size_t)t * B + bidx) * (2 * HID) + dir * HID + unit];
         }
         return s;
     };
-    Saved sv[NT];
-    {
-        const int t = dir ? 0 : T - 1;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) sv[nt] = load_saved(t, nt);
-    }
-    __syncthreads();
+    Saved sv = load_saved(dir ? 0 : T - 1);
 
     for (int step = 0; step < T; ++step) {
         const int t = dir ? step : T - 1 - step;
-        Saved sn[NT];
-        if (step + 1 < T) {
-            const int tn = dir ? t + 1 : t - 1;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) sn[nt] = load_saved(tn, nt);
-        }
-        float dh_rec[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) dh_rec[nt] = carry[nt];
+        Saved sn; sn.gt = make_float4(0, 0, 0, 0); sn.ct = sn.cp = sn.dy = 0.f;
+        if (step + 1 < T) sn = load_saved(dir ? t + 1 : t - 1);
+        float dh_rec = carry;
 
         if (step > 0) {
-            if (w == 0) {
-                if (!wait_counter(ctr, (unsigned)(G_CLUSTER * step))) { s_abort = 1; *a.err = 1; }
-            }
-            __syncthreads();
-            if (s_abort) break;
-            const int p = (step - 1) & 1;
+            const unsigned pbase = (unsigned)((step - 1) & 1) * SLOT + (unsigned)((pn * 256 + unit) * 4);
+            const unsigned stale_bit = (((step - 1) >> 1) & 1) ? 0x2u : 0x1u;
+            float v[16];
+            SpinGuard sg;
+            while (true) {
+                unsigned orr = 0;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                bf16x8 Dhi[8], Dlo[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int kc = 4 * (8 * w + i) + q;
-                    const unsigned off = (unsigned)(((((p * NT + nt) * 128 + kc) * 16 + n) * 2) * 16);
-                    Dhi[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16));
-                    Dlo[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 16));
+                for (int s = 0; s < 16; ++s) {
+                    const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(rsrc, pbase + (unsigned)s * (16 * 256 * 4), 0, 16);
+                    orr |= u;
+                    v[s] = __uint_as_float(u);
                 }
-                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[i], Dhi[i], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[i], Dlo[i], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wlo[i], Dhi[i], acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) part[((nt * 4 + w) * 16 + (4 * q + j)) * 16 + n] = acc[j];
+                if (!__any((orr & stale_bit) != 0)) break;
+                if (s_abort || !sg.keep_waiting()) { s_abort = 1; *a.err = 1; break; }
             }
-            __syncthreads();
+            float s0 = 0.f;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float* pp = &part[(nt * 4 * 16 + ul) * 16 + pn];
-                dh_rec[nt] += (pp[0] + pp[256]) + (pp[512] + pp[768]);
-            }
+            for (int s = 0; s < 16; ++s) s0 += v[s];     // fixed order: reproducible
+            dh_rec += s0;
         }
-        float4 dgt[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const bool active = t < len[nt];
-            const float gi = sv[nt].gt.x, gf = sv[nt].gt.y, gg = sv[nt].gt.z, go = sv[nt].gt.w;
-            const float dh = sv[nt].dy + dh_rec[nt];
-            const float tc = tanhf_fast(sv[nt].ct);
-            const float dct = dh * go * (1.f - tc * tc) + dc[nt];
-            float4 d;
-            d.x = dct * gg * gi * (1.f - gi);
-            d.y = dct * sv[nt].cp * gf * (1.f - gf);
-            d.z = dct * gi * (1.f - gg * gg);
-            d.w = dh * tc * go * (1.f - go);
-            if (active) { dc[nt] = dct * gf; carry[nt] = 0.f; }
-            else { d = make_float4(0, 0, 0, 0); carry[nt] = dh_rec[nt]; }
-            dgt[nt] = d;
+        const bool active = t < len;
+        const float gi = sv.gt.x, gf = sv.gt.y, gg = sv.gt.z, go = sv.gt.w;
+        const float dh = sv.dy + dh_rec;
+        const float tc = tanhf_fast(sv.ct);
+        const float dct = dh * go * (1.f - tc * tc) + dc;
+        float4 d;
+        d.x = dct * gg * gi * (1.f - gi);
+        d.y = dct * sv.cp * gf * (1.f - gf);
+        d.z = dct * gi * (1.f - gg * gg);
+        d.w = dh * tc * go * (1.f - go);
+        if (active) { dc = dct * gf; carry = 0.f; }
+        else { d = make_float4(0, 0, 0, 0); carry = dh_rec; }
+        unsigned short* dbuf = &dgl[(step & 1) * (16 * 2 * 64)];
+        {
             unsigned short hi[4], lo[4];
-            split_bf16(d.x, hi[0], lo[0]); split_bf16(d.y, hi[1], lo[1]);
-            split_bf16(d.z, hi[2], lo[2]); split_bf16(d.w, hi[3], lo[3]);
-            // [nt][n][hl][r' local = ul*4 + gate]
-            unsigned short* dst = &dgs[((nt * 16 + pn) * 2) * 64 + ul * 4];
+            split_plain(d.x, hi[0], lo[0]); split_plain(d.y, hi[1], lo[1]);
+            split_plain(d.z, hi[2], lo[2]); split_plain(d.w, hi[3], lo[3]);
+            unsigned short* dst = &dbuf[(pn * 2) * 64 + pu * 4];      // [n][hl][r' local = 4*pu + gate]
             *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
             *reinterpret_cast<uint2*>(dst + 64) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
         }
         __syncthreads();
+        if (s_abort) break;
         if (step + 1 < T) {
-            const int p = step & 1;
-            const int ln = tid >> 4, lhl = (tid >> 3) & 1, lc8 = tid & 7;
+            bf16x8 Dhi[2], Dlo[2];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(&dgs[(nt * 256 + tid) * 8]);
-                const unsigned off = (unsigned)((((((p * NT + nt) * 128 + (8 * g + lc8)) * 16 + ln) * 2) + lhl) * 16);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 16);
+            for (int i = 0; i < 2; ++i) {
+                Dhi[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&dbuf[(n * 2 + 0) * 64 + 32 * i + 8 * q]));
+                Dlo[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&dbuf[(n * 2 + 1) * 64 + 32 * i + 8 * q]));
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+            f32x4 acc[4];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            if (bidx[nt] < B) {
-                const size_t gi = (((size_t)t * B + bidx[nt]) * 2 + dir) * HID + unit;
-                *reinterpret_cast<float4*>(a.gates + gi * 4) = dgt[nt];
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[mt][i], Dhi[i], acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[mt][i], Dlo[i], acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wlo[mt][i], Dhi[i], acc[mt], 0, 0, 0);
             }
-            sv[nt] = sn[nt];
+            const unsigned e = (unsigned)(step >> 1) & 1u;
+            const unsigned tag = e ? 0x1u : 0x2u;       // (bit0, bit1) = (e, 1-e)
+            const unsigned obase = (unsigned)(step & 1) * SLOT + (unsigned)g * (16 * 256 * 4);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                u32x4 o;
+                o.x = (__float_as_uint(acc[mt][0]) & ~3u) | tag;
+                o.y = (__float_as_uint(acc[mt][1]) & ~3u) | tag;
+                o.z = (__float_as_uint(acc[mt][2]) & ~3u) | tag;
+                o.w = (__float_as_uint(acc[mt][3]) & ~3u) | tag;
+                // lane (q,n), tile 4w+mt: output units 16(4w+mt) + 4q .. +3 for utterance n
+                const unsigned off = obase + (unsigned)((n * 256 + 16 * (4 * w + mt) + 4 * q) * 4);
+                if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 0);
+                else          __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 16);
+            }
         }
+        if (bidx < B) {
+            const size_t gi2 = (((size_t)t * B + bidx) * 2 + dir) * HID + unit;
+            *reinterpret_cast<float4*>(a.gates + gi2 * 4) = d;
+        }
+        sv = sn;
     }
 }
 
@@ -461,17 +534,22 @@ __global__ __launch_bounds__(256) void lstm_unpack_kernel(UnpackArgs u) {
     }
 }
 
-struct WsLayout { size_t xbuf, ctr, err, total; };
+struct WsLayout { size_t err, hello, xbuf, xbytes, stamps, total; int NBG, NCL8; };
 WsLayout lstm_ws_layout(int B, bool backward) {
-    const int NT = 1;
-    const int NBG = (B + 16 * NT - 1) / (16 * NT);
     WsLayout l;
-    size_t off = 0;
-    const size_t xregion = (size_t)2 * NT * (backward ? 128 : 32) * 16 * 2 * 16;
-    l.ctr = off; off += (size_t)2 * NBG * 32 * sizeof(unsigned);   // zeroed every call
-    l.err = off; off += 256;
-    l.xbuf = off; off += (size_t)2 * NBG * xregion;
-    l.total = off;
+    l.NBG = (B + 15) / 16;
+    const int ncl = 2 * l.NBG;
+    l.NCL8 = (ncl + 7) / 8 * 8;
+    const size_t slot = backward ? (size_t)16 * 16 * 256 * 4 : (size_t)32 * 16 * 2 * 16;
+    l.err = 0;                                   // 256 bytes
+    l.hello = 256;                               // [clusters][16] words; err+hello zeroed every call
+    l.xbuf = l.hello + pgasr_align_up((size_t)ncl * 16 * sizeof(unsigned), 256);
+    l.xbytes = (size_t)ncl * 2 * slot;           // [cluster][parity][slot], filled with 0x00000001 every call
+    l.stamps = l.xbuf + l.xbytes;
+    l.total = l.stamps;
+#ifdef PGASR_LSTM_STAMPS
+    l.total += (size_t)STAMP_MAX_T * 8 * sizeof(long long);
+#endif
     return l;
 }
 
@@ -525,39 +603,45 @@ extern "C" size_t pgasr_lstm_workspace_bytes(int T, int B, int backward) {
 }
 
 static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, const float* dout, const void* wpack,
-                       const int* lengths, int T, int B, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                       const int* lengths, int T, int B, int flags, void* workspace, size_t workspace_bytes, hipStream_t st) {
     if (!gates || !out || !cbuf || !wpack || !lengths || T <= 0 || B <= 0) return PGASR_ERR_INVALID_ARG;
     if (backward && !dout) return PGASR_ERR_INVALID_ARG;
     const WsLayout l = lstm_ws_layout(B, backward);
     if (!workspace || workspace_bytes < l.total) return PGASR_ERR_WORKSPACE;
-    const int NBG = (B + 15) / 16;
-    // every cluster must be co-resident: 16 * NBG * 2 workgroups, one per CU
-    if (G_CLUSTER * NBG * 2 > 256) return PGASR_ERR_UNSUPPORTED;
+    // every cluster must be co-resident, one workgroup per CU: at most 2 clusters per XCD
+    if (2 * l.NBG > 16) return PGASR_ERR_UNSUPPORTED;
     char* ws = (char*)workspace;
-    if (hipMemsetAsync(ws + l.ctr, 0, l.err + 256 - l.ctr, st) != hipSuccess) return PGASR_ERR_LAUNCH;
+    if (hipMemsetAsync(ws + l.err, 0, l.xbuf - l.err, st) != hipSuccess) return PGASR_ERR_LAUNCH;
+    // every exchange word starts as "stale for epoch 0": bit0 = 1
+    if (hipMemsetD32Async((hipDeviceptr_t)(ws + l.xbuf), 0x00000001, l.xbytes / 4, st) != hipSuccess) return PGASR_ERR_LAUNCH;
     LstmArgs a;
     a.gates = gates; a.out = out; a.cbuf = cbuf; a.dout = dout; a.wpack = (const u32x4*)wpack;
-    a.xbuf = (unsigned char*)(ws + l.xbuf); a.ctr = (unsigned*)(ws + l.ctr); a.err = (int*)(ws + l.err);
-    a.lengths = lengths; a.T = T; a.B = B; a.NBG = NBG;
-    dim3 grid(G_CLUSTER, NBG, 2);
-    if (backward) hipLaunchKernelGGL(lstm_bwd_kernel<1>, grid, dim3(LSTM_THREADS), 0, st, a);
-    else hipLaunchKernelGGL(lstm_fwd_kernel<1>, grid, dim3(LSTM_THREADS), 0, st, a);
+    a.xbuf = (unsigned char*)(ws + l.xbuf); a.hello = (unsigned*)(ws + l.hello); a.err = (int*)(ws + l.err);
+    a.lengths = lengths; a.T = T; a.B = B; a.NBG = l.NBG; a.NCL8 = l.NCL8;
+    a.force_mode = (flags & 1) ? 1 : 0;
+    a.stamps = (long long*)(ws + l.stamps);
+#ifdef PGASR_LSTM_STAMPS
+    if (T > STAMP_MAX_T) return PGASR_ERR_UNSUPPORTED;
+#endif
+    dim3 grid(G_CLUSTER * l.NCL8);
+    if (backward) hipLaunchKernelGGL(lstm_bwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(lstm_fwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }
 
 extern "C" int pgasr_lstm_layer_fwd(float* gates, float* out, float* cbuf, const void* whh_pack_fwd,
-                                    const int32_t* lengths, int T, int B,
+                                    const int32_t* lengths, int T, int B, int flags,
                                     void* workspace, size_t workspace_bytes, void* stream) {
-    return lstm_launch(false, gates, out, cbuf, nullptr, whh_pack_fwd, lengths, T, B, workspace, workspace_bytes,
+    return lstm_launch(false, gates, out, cbuf, nullptr, whh_pack_fwd, lengths, T, B, flags, workspace, workspace_bytes,
                        (hipStream_t)stream);
 }
 
 extern "C" int pgasr_lstm_layer_bwd(float* gates, const float* out, const float* cbuf, const float* dout,
-                                    const void* whh_pack_bwd, const int32_t* lengths, int T, int B,
+                                    const void* whh_pack_bwd, const int32_t* lengths, int T, int B, int flags,
                                     void* workspace, size_t workspace_bytes, void* stream) {
     return lstm_launch(true, gates, const_cast<float*>(out), const_cast<float*>(cbuf), dout, whh_pack_bwd, lengths, T, B,
-                       workspace, workspace_bytes, (hipStream_t)stream);
+                       flags, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // reads the error word written by a timed-out wait (host-side check after a sync)

@@ -252,11 +252,14 @@ def _lstm_ws(T, B, backward, device):
     return _workspace(nbytes, device, "lstm_bwd" if backward else "lstm_fwd")
 
 
+LSTM_FLAGS = 0   # bit 0: force the write-through (cross-XCD) hand-off protocol
+
+
 def lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B):
     lib = _lib.load()
     ws = _lstm_ws(T, B, False, gates.device)
     with _timed("lstm_fwd_kernel"):
-        st = lib.pgasr_lstm_layer_fwd(_p(gates), _p(out), _p(cbuf), _p(pack_f), _p(lengths), T, B, _p(ws), ws.numel(), _stream())
+        st = lib.pgasr_lstm_layer_fwd(_p(gates), _p(out), _p(cbuf), _p(pack_f), _p(lengths), T, B, LSTM_FLAGS, _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_lstm_layer_fwd")
     return ws
 
@@ -265,7 +268,7 @@ def lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B):
     lib = _lib.load()
     ws = _lstm_ws(T, B, True, gates.device)
     with _timed("lstm_bwd_kernel"):
-        st = lib.pgasr_lstm_layer_bwd(_p(gates), _p(out), _p(cbuf), _p(dout), _p(pack_b), _p(lengths), T, B,
+        st = lib.pgasr_lstm_layer_bwd(_p(gates), _p(out), _p(cbuf), _p(dout), _p(pack_b), _p(lengths), T, B, LSTM_FLAGS,
                                       _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_lstm_layer_bwd")
     return ws

@@ -96,6 +96,30 @@ def test_blstm_layer_vs_torch_cpu(T, B, lens):
         assert rel_err(p.grad.cpu(), getattr(lstm, n).grad) < 1e-3, n
 
 
+def test_blstm_write_through_protocol_matches_default():
+    """flags bit 0 forces the cross-XCD (write-through) hand-off; results must be identical to the
+    default (placement-selected) protocol bit for bit."""
+    from policy_gradient_asr_amd import functional as Fh, hipops
+    T, B, lens = 50, 20, [50] * 10 + list(range(40, 30, -1))
+    lstm, x, dy, lengths = _lstm_case(T, B, lens, seed=5)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0",
+             "weight_ih_l0_reverse", "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+    res = []
+    for flags in (0, 1):
+        hipops.LSTM_FLAGS = flags
+        try:
+            params = [getattr(lstm, n).detach().to(DEV).requires_grad_(True) for n in names]
+            xg = x.to(DEV).requires_grad_(True)
+            y = Fh.blstm_layer(xg, lengths.to(torch.int32).to(DEV), params)
+            y.backward(dy.to(DEV))
+            torch.cuda.synchronize()
+            res.append([y.detach().cpu(), xg.grad.cpu()] + [p.grad.cpu() for p in params])
+        finally:
+            hipops.LSTM_FLAGS = 0
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_encoder_matches_reference_golden(golden_dir):
     """Encoder on the MI355X vs the reference model.Encoder outputs (tests/golden)."""
     from policy_gradient_asr_amd.model import Encoder

@@ -22,3 +22,21 @@ torch.cuda.synchronize()
 print(f"3 steps: {(time.perf_counter()-t0)*1e3/3:.1f} ms/step", flush=True)
 for k, (ms, n) in hipops.profile_collect().items():
     print(f"  {k}: {ms/3:.2f} ms/step over {n/3:.0f} launches", flush=True)
+
+# ---- precision of one BLSTM layer vs fp64 torch-CPU (T=300,B=16) ----
+import numpy as np
+from policy_gradient_asr_amd import functional as Fh
+g = torch.Generator().manual_seed(0)
+Tn, Bn = 300, 16
+lstm = torch.nn.LSTM(512, 256, 1, bidirectional=True).double()
+xx = torch.randn(Tn, Bn, 512, generator=g).double(); dy = torch.randn(Tn, Bn, 512, generator=g).double() * 1e-4
+xr = xx.clone().requires_grad_(True)
+o, _ = lstm(xr); o.backward(dy)
+names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+ps = [getattr(lstm, n_).detach().float().to(dev).requires_grad_(True) for n_ in names]
+xg = xx.float().to(dev).requires_grad_(True)
+y = Fh.blstm_layer(xg, torch.full((Bn,), Tn, dtype=torch.int32, device=dev), ps)
+y.backward(dy.float().to(dev)); torch.cuda.synchronize()
+re = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())
+print(f"precision: out {re(y.detach(), o.detach()):.2e}  dx {re(xg.grad, xr.grad):.2e}  " +
+      "  ".join(f"{n_[7:]} {re(p_.grad, getattr(lstm, n_).grad):.2e}" for n_, p_ in zip(names, ps)), flush=True)
