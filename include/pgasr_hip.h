@@ -184,6 +184,22 @@ int pgasr_lstm_layer_bwd(float* gates, const float* out, const float* cbuf, cons
                          const void* whh_pack_bwd, const int32_t* lengths, int T, int B, int flags,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * A7  CTC prefix beam search (CTCdecoder.py:41-116), one workgroup per utterance.
+ *   log_probs: natural-log probabilities, element (t,b,v) at log_probs[t*stride_t + b*stride_b + v],
+ *              fp32 (is_f64 = 0) or fp64 (is_f64 != 0; the drop-in CTCDecoder.decode passes
+ *              numpy's log of its probability matrix, like CTCdecoder.py:55);
+ *   lengths (B) frames per utterance (NULL = T); beam <= 128, V <= 64, beam*V LDS-limited.
+ *   out_tokens (B,T) best prefix, out_len (B), out_score (B) = -logsumexp(p_blank, p_nonblank)
+ *   of that prefix (CTCdecoder.py:115-116).  Candidate order, prefix merging and the stable
+ *   descending sort (ties -> first insertion) follow the reference exactly; scores are fp64.
+ * ---------------------------------------------------------------------------------------- */
+size_t pgasr_beam_workspace_bytes(int T, int B, int V, int beam);
+int pgasr_ctc_beam_search(const void* log_probs, int is_f64, long long stride_t, long long stride_b,
+                          const int32_t* lengths, int T, int B, int V, int beam, int blank,
+                          int32_t* out_tokens, int32_t* out_len, double* out_score,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,9 @@ SIGNATURES = {
                                       c_i32p, c_i32p, c_ptr]),
     "pgasr_reinforce_grad": (C.c_int, [c_f32p, c_i32p, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        c_f32p, c_ptr]),
+    "pgasr_beam_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "pgasr_ctc_beam_search": (C.c_int, [c_ptr, C.c_int, C.c_longlong, C.c_longlong, c_i32p, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, c_i32p, c_i32p, c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "pgasr_gemm_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "pgasr_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                  c_f32p, C.c_int, C.c_longlong, c_f32p, C.c_int, C.c_longlong,

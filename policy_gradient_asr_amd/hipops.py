@@ -283,3 +283,28 @@ def lstm_check_error(ws, B, backward):
     flag = int(ws[off.value:off.value + 4].view(torch.int32).item())
     if flag != 0:
         raise _lib.PgasrError("persistent LSTM sweep timed out waiting for its cluster (status 5)")
+
+
+# ------------------------------------------------------------------------------------------
+# prefix beam search
+# ------------------------------------------------------------------------------------------
+def ctc_beam_search(log_probs, lengths=None, beam=5, blank=0):
+    """log_probs (T,B,V) fp32 or fp64 natural-log probabilities on the GPU.
+    Returns (tokens (B,T) int32, token_lengths (B) int32, score (B) float64 = -log p)."""
+    lib = _lib.load()
+    if not log_probs.is_cuda or log_probs.dtype not in (torch.float32, torch.float64):
+        raise _lib.PgasrError("log_probs must be a float32/float64 GPU tensor")
+    if log_probs.stride(2) != 1:
+        raise _lib.PgasrError("log_probs must be contiguous in its last dimension")
+    T, B, V = log_probs.shape
+    _req(lengths, torch.int32, "lengths")
+    nbytes = lib.pgasr_beam_workspace_bytes(T, B, V, beam)
+    ws = _workspace(nbytes, log_probs.device, "beam")
+    tokens = torch.zeros(B, T, dtype=torch.int32, device=log_probs.device)
+    tl = torch.empty(B, dtype=torch.int32, device=log_probs.device)
+    score = torch.empty(B, dtype=torch.float64, device=log_probs.device)
+    st = lib.pgasr_ctc_beam_search(_p(log_probs), int(log_probs.dtype == torch.float64), log_probs.stride(0),
+                                   log_probs.stride(1), _p(lengths), T, B, V, int(beam), int(blank),
+                                   _p(tokens), _p(tl), _p(score), _p(ws), ws.numel(), _stream())
+    _lib.check(st, "pgasr_ctc_beam_search")
+    return tokens, tl, score

@@ -1,0 +1,116 @@
+"""Beam search / metrics / reward drop-ins against the reference's own outputs (tests/golden)
+and the oracle.  Integer outputs bit-exact; scores to 1e-9 relative (fp64 device math)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decode_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def vectors(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "reference_vectors.json")))
+
+
+@pytest.fixture(scope="module")
+def beam_inputs(golden_dir):
+    return np.load(os.path.join(golden_dir, "beam_inputs.npz"))
+
+
+def test_beam_decode_matches_reference_golden(vectors, beam_inputs):
+    from policy_gradient_asr_amd.CTCdecoder import CTCDecoder
+    dec = CTCDecoder([chr(97 + i) for i in range(29)])
+    for case in vectors["beam"]:
+        probs = beam_inputs[case["key"]]
+        prefix, nll = dec.decode(probs, beam_size=case["beam"])
+        assert list(prefix) == case["prefix"], case
+        if np.isfinite(case["nll"]):
+            assert nll == pytest.approx(case["nll"], rel=1e-9, abs=1e-9), case
+        else:
+            assert nll == case["nll"]
+
+
+def test_beam_batch_fp32_vs_oracle_and_lengths():
+    from policy_gradient_asr_amd.CTCdecoder import CTCDecoder
+    T, B, V = 120, 5, 29
+    rng = np.random.default_rng(3)
+    logits = rng.normal(size=(T, B, V)) * 3
+    logits[:, :, 0] += 2
+    lp = torch.log_softmax(torch.tensor(logits, dtype=torch.float32), 2)
+    lens = np.array([120, 77, 1, 0, 100], dtype=np.int32)
+    dec = CTCDecoder(list(range(V)))
+    tok, tl, score = dec.decode_batch(lp.to(DEV), torch.from_numpy(lens).to(DEV), beam_size=16)
+    for b in range(B):
+        probs = np.exp(lp[:lens[b], b].double().numpy())
+        if lens[b] == 0:
+            assert tl[b] == 0
+            continue
+        want, nll = decode_ref.prefix_beam_search(probs, beam_size=16)
+        assert list(tok[b, :tl[b]].cpu().numpy()) == list(want)
+        assert float(score[b]) == pytest.approx(nll, rel=1e-6)
+
+
+def test_beam_headline_size_properties():
+    """T=1000,B=32,beam=16: runs, scores finite and never better than the CTC total."""
+    from policy_gradient_asr_amd import hipops
+    T, B, V = 1000, 32, 29
+    g = torch.Generator().manual_seed(0)
+    lp = torch.log_softmax(torch.randn(T, B, V, generator=g) * 2, 2).to(DEV)
+    tok, tl, score = hipops.ctc_beam_search(lp, None, beam=16)
+    assert torch.isfinite(score).all() and (tl >= 0).all() and (tl <= T).all()
+    # beam 1 prefix mass <= beam 16 best prefix mass is not guaranteed; but a prefix's nll is >= 0
+    assert (score >= 0).all()
+    # no repeated blank tokens in output and tokens within vocabulary
+    for b in (0, 13, 31):
+        seq = tok[b, :tl[b]]
+        assert ((seq >= 1) & (seq < V)).all()
+
+
+def test_collapse_fn_and_greedy(vectors):
+    from policy_gradient_asr_amd.CTCdecoder import collapse_fn, greedy_decode
+    for s, want in vectors["text"]["collapse_fn"]:
+        assert collapse_fn(s) == want
+    g = torch.Generator().manual_seed(2)
+    sc = torch.randn(90, 4, 29, generator=g)
+    lens = torch.tensor([90, 50, 0, 7], dtype=torch.int32)
+    tok, tl = greedy_decode(sc.to(DEV), lens.to(DEV))
+    want = decode_ref.greedy_decode(sc.numpy(), lens.numpy())
+    for b in range(4):
+        assert list(tok[b, :tl[b]].cpu().numpy()) == want[b]
+
+
+def test_metrics_dropins(vectors, tmp_path):
+    from policy_gradient_asr_amd import metrics
+    for a, b, want in vectors["text"]["edit_dist"]:
+        assert list(metrics.edit_dist(a, b)) == want
+    for a, b, want in vectors["text"]["edit_dist_tokens"]:
+        assert list(metrics.edit_dist(a, b)) == want
+    for a, b, want in vectors["text"]["evaluate"]:
+        got = metrics.evaluate(a, b)
+        assert got[0] == pytest.approx(want[0]) and got[1] == pytest.approx(want[1])
+    with pytest.raises(ZeroDivisionError):
+        metrics.evaluate("", "abc")
+    metrics.save_predictions(["a b", "c"], ["a", "c d"], str(tmp_path))
+    assert open(tmp_path / "predicted.txt").read() == "a b|a\nc|c d\n"
+
+
+def test_reward_dropin(vectors):
+    from policy_gradient_asr_amd.CTCdecoder import CTCDecoder
+    from policy_gradient_asr_amd.policy_grad import reward, rewards_all_t
+    rd = vectors["reward_defect"]
+    probs = np.array(rd["probs"]); y = rd["true_y"]
+    ind2char = {0: "<pad>", 1: "a", 2: "b", 3: "c"}
+    dec = CTCDecoder(["<pad>", "a", "b", "c"])
+    rs, s = rewards_all_t(y, probs, ind2char, dec)
+    assert s == rd["decoded_collapsed"]
+    for t in range(1, len(s) + 1):
+        assert reward(y, probs, t, ind2char, dec) == decode_ref.reward_from_string(y, s, t) == rs[t - 1]
+    assert reward(y, probs, len(s) + 3, ind2char, dec) == 0
+    with pytest.raises(ValueError):
+        reward(y, probs, 0, ind2char, dec)
