@@ -3,12 +3,12 @@ per GPU, gradients all-reduced over RCCL (replaces nn.DataParallel, model.py:201
 
 Parameters and gradients live in two flat fp32 buffers (nn.Parameters are views), so the
 data-parallel exchange is ONE all-reduce of the whole gradient (19.15 MB at F=80,V=29) and the
-optimizer is one Adam over the flat buffer.  The loss is normalised by the GLOBAL batch so 1-GPU
-and N-GPU gradients agree to fp32 rounding."""
+optimizer is one Adam over the flat buffer.  Utterances are independent through forward, CTC,
+decode, reward and REINFORCE gradient, so the gradient all-reduce is the only collective; the loss
+is normalised by the GLOBAL batch so 1-GPU and N-GPU gradients agree to fp32 rounding.
+"""
 import torch
 import torch.distributed as dist
-
-from .loss import pg_ctc_loss
 
 
 def flatten_parameters(model):
@@ -29,40 +29,85 @@ def flatten_parameters(model):
     return flat, gflat
 
 
-class PolicyGradientTrainer:
-    """step(batch) = H2D-ready batch -> forward -> CTC + REINFORCE loss -> backward -> all-reduce -> Adam.
-    Optimizer: Adam(lr=5e-4), the reference's commented choice (model.py:207)."""
+def shard_slice(global_batch, rank, world):
+    """Contiguous B/N utterances per rank (global_batch must divide evenly)."""
+    if global_batch % world:
+        raise ValueError("global batch must be a multiple of the world size")
+    per = global_batch // world
+    return slice(rank * per, (rank + 1) * per)
 
-    def __init__(self, model, lr=5e-4, lam=1.0, seed=0, blank=0, world_size=1, process_group=None):
+
+def balance_by_frames(lengths, world):
+    """Variable-T batches (BASELINE config 5): assign utterances to ranks so that every rank gets
+    the same COUNT and nearly the same total number of frames (ranks then reach the all-reduce
+    together).  Greedy longest-first into the lightest non-full rank.  Returns a list of index
+    lists, one per rank."""
+    n = len(lengths)
+    if n % world:
+        raise ValueError("batch must be a multiple of the world size")
+    per = n // world
+    order = sorted(range(n), key=lambda i: -int(lengths[i]))
+    loads = [0] * world
+    out = [[] for _ in range(world)]
+    for i in order:
+        r = min((r for r in range(world) if len(out[r]) < per), key=lambda r: loads[r])
+        out[r].append(i)
+        loads[r] += int(lengths[i])
+    return out
+
+
+class DataParallelStep:
+    """zero_grad -> forward_loss -> backward -> all-reduce(sum) -> Adam, on flat buffers.
+    Subclasses provide ``forward_loss(batch, global_batch) -> scalar loss`` already divided by the
+    GLOBAL batch size, so the summed gradient is the global-batch gradient."""
+
+    def __init__(self, model, lr=5e-4, world_size=1, process_group=None):
         self.model = model
-        self.lam = lam
-        self.seed = seed
-        self.blank = blank
         self.world = world_size
         self.pg = process_group
         self.flat, self.gflat = flatten_parameters(model)
         self.flat_param = torch.nn.Parameter(self.flat)
         self.flat_param.grad = self.gflat
-        self.opt = torch.optim.Adam([self.flat_param], lr=lr, fused=self.flat.is_cuda)
+        # Adam(lr=5e-4) is the reference's commented choice (model.py:207)
+        self.opt = torch.optim.Adam([self.flat_param], lr=lr, fused=bool(self.flat.is_cuda))
         self.nstep = 0
         if self.world > 1:
-            dist.broadcast(self.flat, src=0, group=self.pg)
+            dist.broadcast(self.flat, src=0, group=self.pg)   # identical replicas
 
-    def step(self, x, targets, fmask, tmask):
-        """x (B,F,T) fp32; targets (B,L) int (pad 0); fmask (B,T); tmask (B,L).  Returns the
-        detached loss tensor (no host sync)."""
-        model = self.model
-        B = x.shape[0]
-        tg_len = tmask.sum(dim=1).to(torch.int32).contiguous()
-        tg = targets.to(torch.int32).contiguous()
+    def forward_loss(self, batch, global_batch):  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def step(self, *batch):
+        local_b = batch[0].shape[0]
         self.gflat.zero_()
-        logits, in_len = model.logits(x, fmask)
-        loss, nll, R_s, R_g = pg_ctc_loss(logits, in_len, tg, tg_len, lam=self.lam, seed=self.seed,
-                                          offset=self.nstep, global_batch=B * self.world, blank=self.blank)
+        loss = self.forward_loss(batch, local_b * self.world)
         loss.backward()
         if self.world > 1:
             dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.pg)
         self.opt.step()
         self.nstep += 1
-        self.last_stats = (nll, R_s, R_g)
         return loss.detach()
+
+
+class PolicyGradientTrainer(DataParallelStep):
+    """step(x, targets, fmask, tmask): x (B,F,T) fp32; targets (B,L) int (pad 0); fmask (B,T);
+    tmask (B,L) -- the collate_custom batch (data.py:107-116) after model.py:227-230's squeeze.
+    Returns the detached local loss (no host sync)."""
+
+    def __init__(self, model, lr=5e-4, lam=1.0, seed=0, blank=0, world_size=1, process_group=None, rank=0):
+        super().__init__(model, lr=lr, world_size=world_size, process_group=process_group)
+        self.lam = lam
+        self.seed = seed + 7919 * rank     # independent sample streams per rank
+        self.blank = blank
+        self.last_stats = None
+
+    def forward_loss(self, batch, global_batch):
+        from .loss import pg_ctc_loss
+        x, targets, fmask, tmask = batch
+        tg_len = tmask.sum(dim=1).to(torch.int32).contiguous()
+        tg = targets.to(torch.int32).contiguous()
+        logits, in_len = self.model.logits(x, fmask)
+        loss, nll, R_s, R_g = pg_ctc_loss(logits, in_len, tg, tg_len, lam=self.lam, seed=self.seed,
+                                          offset=self.nstep, global_batch=global_batch, blank=self.blank)
+        self.last_stats = (nll, R_s, R_g)
+        return loss
