@@ -119,6 +119,9 @@ int pgasr_reinforce_grad(const float* scores, const int32_t* path, const float* 
  *   (model.py:50); dact_y != NULL multiplies by d leaky_relu evaluated on dact_y (same layout as C);
  *   accumulate != 0 adds to C.  norm_operand 1/2 applies (x - shift[b]) * scale[b] to A/B while
  *   the tile is loaded: the per-utterance InstanceNorm2d of model.py:37,48 fused into the affine.
+ *   precision 0: exact fp32 MFMA.  precision 1: each operand element is split into bf16 hi+lo while
+ *   staged and the product is hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation
+ *   (~1e-6 relative; ~5x the fp32 matrix rate); not combinable with norm_operand.
  * ---------------------------------------------------------------------------------------- */
 size_t pgasr_gemm_workspace_bytes(int M, int N, int batch, int splitk, int sum_batches);
 int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
@@ -128,7 +131,7 @@ int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                    int batch, int sum_batches, int splitk,
                    const float* bias, const float* bias2, int act, float slope, int accumulate,
                    const float* dact_y, int norm_operand, const float* shift, const float* scale,
-                   void* workspace, size_t workspace_bytes, void* stream);
+                   int precision, void* workspace, size_t workspace_bytes, void* stream);
 
 /* column sums of X (rows x cols, leading dim ld) -> out (and out2 if non-NULL): bias gradients. */
 size_t pgasr_colsum_workspace_bytes(int rows, int cols);

@@ -84,15 +84,30 @@ __device__ __forceinline__ void store_strip(float (*S)[BM + PADF], int tid, cons
     }
 }
 
+// XCD-aware tile order (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8
+// XCDs, so consecutive linear ids land on different L2s.  Remap so that each XCD walks one
+// CONTIGUOUS chunk of the (x fastest) tile order: tiles that share an operand panel then share
+// an L2.  Bijective for any grid size; placement affects speed only.
+__device__ __forceinline__ void swizzled_tile(int& bx, int& by, int& bz) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const unsigned nwg = gx * gy * gz;
+    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned q = nwg / 8, r = nwg % 8;
+    const unsigned xcd = L % 8, i = L / 8;
+    const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    bx = (int)(t % gx); by = (int)((t / gx) % gy); bz = (int)(t / (gx * gy));
+}
+
 template <bool TA, bool TB>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM + PADF];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PADF];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int z = blockIdx.z;
+    int tbx, tby, z;
+    swizzled_tile(tbx, tby, z);
     const int bidx = z / g.splitk, sidx = z % g.splitk;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = tby * BM, n0 = tbx * BN;
     const float* A = g.A + (size_t)bidx * g.sA;
     const float* B = g.B + (size_t)bidx * g.sB;
     const int kbeg = sidx * g.kper;
@@ -205,6 +220,199 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16x3 variant: same tiling and epilogue, but each fp32 operand element is split ONCE per tile
+// into bf16 hi + lo while it is staged into LDS (v_cvt_pk_bf16_f32), and every 16-deep k-step
+// issues hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate, so ~5x after
+// the 3 terms).  fp32 accumulate; dropping lo*lo leaves ~2^-16 relative error per product
+// (measured ~1e-6 relative on the path's GEMMs).  LDS image per operand: [row][32 k + 8 pad] bf16,
+// k fastest, so a fragment is one aligned 16-byte read and 16 consecutive rows fall on distinct
+// banks; sources whose M/N index is contiguous (K x M weight-gradient operands) are transposed by
+// the staging writes.
+// ------------------------------------------------------------------------------------------
+constexpr int XBK = 32, XPITCH = 40;   // halfs per LDS row
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi_pk, unsigned& lo_pk) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    const bf2 h = __builtin_convertvector((f2){x0, x1}, bf2);
+    hi_pk = __builtin_bit_cast(unsigned, h);
+    const float h0 = __uint_as_float(hi_pk << 16), h1 = __uint_as_float(hi_pk & 0xFFFF0000u);
+    const bf2 l = __builtin_convertvector((f2){x0 - h0, x1 - h1}, bf2);
+    lo_pk = __builtin_bit_cast(unsigned, l);
+}
+
+// 16-float strip of a 128 x 32 operand tile.
+//   KCONTIG : thread -> (row = tid>>1, k0 = (tid&1)*16)
+//   !KCONTIG: thread -> (k = tid&31, row0 = (tid>>5)*16)
+template <bool KCONTIG>
+__device__ __forceinline__ void xload_strip(const float* __restrict__ P, int ld, int mn_base, int mn_lim,
+                                            int k_base, int k_lim, int tid, bool vec_ok, float v[16]) {
+    if (KCONTIG) {
+        const int mn = mn_base + (tid >> 1);
+        const int k0 = k_base + (tid & 1) * 16;
+        if (mn < mn_lim && k0 + 16 <= k_lim && vec_ok) {
+            const float4* p = reinterpret_cast<const float4*>(P + (size_t)mn * ld + k0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float4 a = p[i]; v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = (mn < mn_lim && k0 + i < k_lim) ? P[(size_t)mn * ld + k0 + i] : 0.f;
+        }
+    } else {
+        const int k = k_base + (tid & 31);
+        const int mn0 = mn_base + (tid >> 5) * 16;
+        if (k < k_lim && mn0 + 16 <= mn_lim && vec_ok) {
+            const float4* p = reinterpret_cast<const float4*>(P + (size_t)k * ld + mn0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float4 a = p[i]; v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = (k < k_lim && mn0 + i < mn_lim) ? P[(size_t)k * ld + mn0 + i] : 0.f;
+        }
+    }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void xstore_strip(unsigned short* hi, unsigned short* lo, int tid, const float v[16]) {
+    if (KCONTIG) {
+        const int row = tid >> 1, k0 = (tid & 1) * 16;
+        unsigned h[8], l[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) split2(v[2 * i], v[2 * i + 1], h[i], l[i]);
+        u32x4_t* ph = reinterpret_cast<u32x4_t*>(hi + row * XPITCH + k0);
+        u32x4_t* pl = reinterpret_cast<u32x4_t*>(lo + row * XPITCH + k0);
+        ph[0] = (u32x4_t){h[0], h[1], h[2], h[3]}; ph[1] = (u32x4_t){h[4], h[5], h[6], h[7]};
+        pl[0] = (u32x4_t){l[0], l[1], l[2], l[3]}; pl[1] = (u32x4_t){l[4], l[5], l[6], l[7]};
+    } else {
+        const int k = tid & 31, row0 = (tid >> 5) * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned h, l;
+            split2(v[2 * i], v[2 * i + 1], h, l);
+            hi[(row0 + 2 * i) * XPITCH + k] = (unsigned short)h;
+            hi[(row0 + 2 * i + 1) * XPITCH + k] = (unsigned short)(h >> 16);
+            lo[(row0 + 2 * i) * XPITCH + k] = (unsigned short)l;
+            lo[(row0 + 2 * i + 1) * XPITCH + k] = (unsigned short)(l >> 16);
+        }
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(GemmArgs g) {
+    // [buffer][operand A/B][plane hi/lo][128 rows][XPITCH]
+    __shared__ __attribute__((aligned(16))) unsigned short S[2][2][2][BM * XPITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    int tbx, tby, z;
+    swizzled_tile(tbx, tby, z);
+    const int bidx = z / g.splitk, sidx = z % g.splitk;
+    const int m0 = tby * BM, n0 = tbx * BN;
+    const float* A = g.A + (size_t)bidx * g.sA;
+    const float* B = g.B + (size_t)bidx * g.sB;
+    const int kbeg = sidx * g.kper;
+    const int kend = min(g.K, kbeg + g.kper);
+    const bool vecA = ((g.lda & 3) == 0) && ((((size_t)A) & 15) == 0);
+    const bool vecB = ((g.ldb & 3) == 0) && ((((size_t)B) & 15) == 0);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // Two register sets: the loads of tile t+2 are issued while tile t is multiplied and tile t+1
+    // (loaded one iteration earlier) is split and written to the other LDS buffer, so a load has
+    // almost two iterations to land (the one-deep version spent 55 % of its wave cycles in
+    // s_waitcnt: rocprofv3 SQ_WAIT_ANY, profiles/r01_gemm_pmc.txt).
+    float ra0[16], rb0[16], ra1[16], rb1[16];
+    const int fr = lane & 31, fk = (lane >> 5) * 8;
+    auto compute = [&](int cur) {
+#pragma unroll
+        for (int kk = 0; kk < XBK; kk += 16) {
+            bf16x8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ro = (wm * 64 + i * 32 + fr) * XPITCH + kk + fk;
+                ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(&S[cur][0][0][ro]));
+                al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(&S[cur][0][1][ro]));
+                const int co = (wn * 64 + i * 32 + fr) * XPITCH + kk + fk;
+                bh[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(&S[cur][1][0][co]));
+                bl[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(&S[cur][1][1][co]));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+#define XLOAD(RA, RB, KB) do { xload_strip<!TA>(A, g.lda, m0, g.M, (KB), kend, tid, vecA, RA); \
+                               xload_strip<TB>(B, g.ldb, n0, g.N, (KB), kend, tid, vecB, RB); } while (0)
+#define XSTORE(RA, RB, BUF) do { xstore_strip<!TA>(S[BUF][0][0], S[BUF][0][1], tid, RA); \
+                                 xstore_strip<TB>(S[BUF][1][0], S[BUF][1][1], tid, RB); } while (0)
+    if (kbeg < kend) {
+        XLOAD(ra0, rb0, kbeg);
+        XSTORE(ra0, rb0, 0);
+        if (kbeg + XBK < kend) XLOAD(ra0, rb0, kbeg + XBK);
+    }
+    __syncthreads();
+    for (int kb = kbeg; kb < kend; kb += 2 * XBK) {
+        // even tile: pending set 0 (tile kb+XBK), free set 1
+        if (kb + 2 * XBK < kend) XLOAD(ra1, rb1, kb + 2 * XBK);
+        compute(0);
+        if (kb + XBK < kend) XSTORE(ra0, rb0, 1);
+        __syncthreads();
+        if (kb + XBK >= kend) break;
+        // odd tile: pending set 1 (tile kb+2*XBK), free set 0
+        if (kb + 3 * XBK < kend) XLOAD(ra0, rb0, kb + 3 * XBK);
+        compute(1);
+        if (kb + 2 * XBK < kend) XSTORE(ra1, rb1, 0);
+        __syncthreads();
+    }
+#undef XLOAD
+#undef XSTORE
+
+    // epilogue (identical to the fp32 kernel: the 32x32 accumulator layout is dtype independent)
+    const int cl = lane & 31, rq = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + cl;
+            if (n >= g.N) continue;
+            float bsum = 0.f;
+            if (!g.partial) {
+                if (g.bias) bsum += g.bias[n];
+                if (g.bias2) bsum += g.bias2[n];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+                if (m >= g.M) continue;
+                float v = g.alpha * acc[i][j][r];
+                if (g.partial) {
+                    g.partial[((size_t)z * g.M + m) * g.N + n] = v;
+                } else {
+                    float* c = g.C + (size_t)bidx * g.sC + (size_t)m * g.ldc + n;
+                    v += bsum;
+                    if (g.act == 1) v = v > 0.f ? v : v * g.slope;
+                    if (g.dact_y) v *= (g.dact_y[(size_t)bidx * g.sC + (size_t)m * g.ldc + n] > 0.f ? 1.f : g.slope);
+                    if (g.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+}
+
 // Sum the Z partial slabs in index order (deterministic) and apply the epilogue.
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float* __restrict__ partial, int Z, int M, int N,
                                                           float* __restrict__ C, int ldc, long long sC,
@@ -275,8 +483,8 @@ __global__ __launch_bounds__(1024) void instnorm_stats_kernel(const float* __res
 
 }  // namespace
 
-static int gemm_launch(GemmArgs& g, int transA, int transB, int sum_batches, void* workspace, size_t workspace_bytes,
-                       hipStream_t st) {
+static int gemm_launch(GemmArgs& g, int transA, int transB, int sum_batches, int precision, void* workspace,
+                       size_t workspace_bytes, hipStream_t st) {
     const int Z = g.batch * g.splitk;
     const bool use_partial = (g.splitk > 1) || sum_batches;
     if (use_partial) {
@@ -288,7 +496,13 @@ static int gemm_launch(GemmArgs& g, int transA, int transB, int sum_batches, voi
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, Z);
     if (grid.y > 65535 || grid.z > 65535) return PGASR_ERR_UNSUPPORTED;
-    if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(GEMM_THREADS), 0, st, g);
+    if (precision == 1) {
+        if (!transA && !transB) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, dim3(GEMM_THREADS), 0, st, g);
+        else if (!transA && transB) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true>), grid, dim3(GEMM_THREADS), 0, st, g);
+        else if (transA && !transB) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), grid, dim3(GEMM_THREADS), 0, st, g);
+        else hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, st, g);
+    }
+    else if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(GEMM_THREADS), 0, st, g);
     else if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(GEMM_THREADS), 0, st, g);
     else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(GEMM_THREADS), 0, st, g);
     else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, st, g);
@@ -317,20 +531,22 @@ extern "C" int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float
                               int batch, int sum_batches, int splitk,
                               const float* bias, const float* bias2, int act, float slope, int accumulate,
                               const float* dact_y, int norm_operand, const float* shift, const float* scale,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+                              int precision, void* workspace, size_t workspace_bytes, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || splitk <= 0) return PGASR_ERR_INVALID_ARG;
     if (norm_operand < 0 || norm_operand > 2 || (norm_operand && (!shift || !scale))) return PGASR_ERR_INVALID_ARG;
-    if (act < 0 || act > 1) return PGASR_ERR_INVALID_ARG;
+    if (act < 0 || act > 1 || precision < 0 || precision > 1) return PGASR_ERR_INVALID_ARG;
+    if (precision == 1 && norm_operand) return PGASR_ERR_UNSUPPORTED;
     if ((splitk > 1 || sum_batches) && dact_y) return PGASR_ERR_INVALID_ARG;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.sA = strideA; g.sB = strideB; g.sC = strideC; g.batch = batch; g.splitk = splitk;
     int kper = (K + splitk - 1) / splitk;
-    kper = (kper + BK - 1) / BK * BK;
+    const int kq = precision == 1 ? XBK : BK;
+    kper = (kper + kq - 1) / kq * kq;
     g.kper = kper;
     g.alpha = alpha; g.bias = bias; g.bias2 = bias2; g.act = act; g.slope = slope; g.accumulate = accumulate;
     g.dact_y = dact_y; g.norm_operand = norm_operand; g.shift = shift; g.scale = scale; g.partial = nullptr;
-    return gemm_launch(g, transA, transB, sum_batches, workspace, workspace_bytes, (hipStream_t)stream);
+    return gemm_launch(g, transA, transB, sum_batches, precision, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" size_t pgasr_colsum_workspace_bytes(int rows, int cols) {

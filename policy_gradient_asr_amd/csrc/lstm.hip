@@ -32,18 +32,21 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-__device__ __forceinline__ unsigned short f2bf(float x) {
-    unsigned u = __float_as_uint(x);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+__device__ __forceinline__ unsigned short f2bf(float x) {   // round to nearest even (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(unsigned short, (__bf16)x);
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ void split_bf16(float x, unsigned short& hi, unsigned short& lo) {
     hi = f2bf(x);
     lo = f2bf(x - bf2f(hi));
 }
-__device__ __forceinline__ float sigmoidf_fast(float x) { return __frcp_rn(1.f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_fast(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+// v_exp_f32 / v_rcp_f32 (1 ulp each): a correctly rounded divide costs ~10 instructions per gate
+__device__ __forceinline__ float sigmoidf_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanhf_fast(float x) {
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.885390081777927f * x));
+}
 
 struct LstmArgs {
     float* gates;            // [T][B][2][H][4]: in = permuted xproj (+biases); out = activations i,f,g,o;
@@ -94,8 +97,12 @@ struct SpinGuard {
     unsigned spins = 0; long long t0 = 0;
     // returns false when the wait has lasted longer than SPIN_TIMEOUT_TICKS
     __device__ __forceinline__ bool keep_waiting() {
-        if (spins == 0) t0 = wall_clock64();
-        if (((++spins) & 1023u) == 0 && wall_clock64() - t0 > SPIN_TIMEOUT_TICKS) return false;
+        // the realtime clock is read only on long waits (never in the common path)
+        if (((++spins) & 1023u) == 0) {
+            const long long now = wall_clock64();
+            if (spins == 1024u) t0 = now;
+            else if (now - t0 > SPIN_TIMEOUT_TICKS) return false;
+        }
         return true;
     }
 };

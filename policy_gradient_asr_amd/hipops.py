@@ -158,13 +158,18 @@ def reinforce_grad(scores, path, coef, lengths, out=None, accumulate=False):
 # ------------------------------------------------------------------------------------------
 # dense contractions
 # ------------------------------------------------------------------------------------------
+GEMM_PRECISION = 1   # default for the model's GEMMs: 1 = bf16x3 split MFMA, 0 = exact fp32 MFMA
+
+
 def gemm(A, B, C, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=None, alpha=1.0,
          strideA=0, strideB=0, strideC=0, batch=1, sum_batches=False, splitk=1, bias=None, bias2=None,
          act=0, slope=0.01, accumulate=False, dact_y=None, norm_operand=0, shift=None, scale=None,
-         a_off=0, b_off=0, c_off=0):
+         a_off=0, b_off=0, c_off=0, precision=None):
     """Raw strided GEMM on device tensors (element offsets a_off/b_off/c_off into A/B/C).
     See include/pgasr_hip.h for the contract."""
     lib = _lib.load()
+    if precision is None:
+        precision = 0 if norm_operand else GEMM_PRECISION
     for t, nm in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (bias2, "bias2"), (dact_y, "dact_y"),
                   (shift, "shift"), (scale, "scale")):
         if t is not None:
@@ -180,7 +185,7 @@ def gemm(A, B, C, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=N
                             A.data_ptr() + 4 * a_off, lda, int(strideA), B.data_ptr() + 4 * b_off, ldb, int(strideB),
                             C.data_ptr() + 4 * c_off, ldc, int(strideC), batch, int(sum_batches), splitk,
                             _p(bias), _p(bias2), act, float(slope), int(accumulate), _p(dact_y),
-                            norm_operand, _p(shift), _p(scale), _p(ws), ws.numel() if ws is not None else 0, _stream())
+                            norm_operand, _p(shift), _p(scale), int(precision), _p(ws), ws.numel() if ws is not None else 0, _stream())
     _lib.check(st, "pgasr_gemm_f32")
     return C
 

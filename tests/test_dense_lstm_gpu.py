@@ -21,7 +21,8 @@ def rel_err(a, b):
     (0, 0, 128, 128, 16), (0, 1, 300, 200, 77), (1, 0, 129, 65, 40), (1, 1, 64, 257, 128),
     (0, 1, 1000, 29, 512), (0, 0, 500, 512, 29), (1, 0, 29, 512, 3000),
 ])
-def test_gemm_layouts(tA, tB, M, N, K):
+@pytest.mark.parametrize("precision,tol", [(0, 1e-5), (1, 3e-5)])
+def test_gemm_layouts(tA, tB, M, N, K, precision, tol):
     from policy_gradient_asr_amd import hipops
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn((K, M) if tA else (M, K), generator=g)
@@ -29,14 +30,14 @@ def test_gemm_layouts(tA, tB, M, N, K):
     bias = torch.randn(N, generator=g)
     want = (A.t() if tA else A).double() @ (B.t() if tB else B).double() + bias.double()
     C = torch.empty(M, N, device=DEV)
-    hipops.gemm(A.to(DEV), B.to(DEV), C, M, N, K, transA=bool(tA), transB=bool(tB), bias=bias.to(DEV))
-    assert rel_err(C.cpu(), want) < 1e-5
+    hipops.gemm(A.to(DEV), B.to(DEV), C, M, N, K, transA=bool(tA), transB=bool(tB), bias=bias.to(DEV), precision=precision)
+    assert rel_err(C.cpu(), want) < tol
     # split-K + accumulate + leaky epilogue
     C2 = torch.ones(M, N, device=DEV)
     hipops.gemm(A.to(DEV), B.to(DEV), C2, M, N, K, transA=bool(tA), transB=bool(tB), splitk=3, bias=bias.to(DEV),
-                act=1, slope=0.01, accumulate=True)
+                act=1, slope=0.01, accumulate=True, precision=precision)
     want2 = torch.nn.functional.leaky_relu(want, 0.01) + 1.0
-    assert rel_err(C2.cpu(), want2) < 1e-5
+    assert rel_err(C2.cpu(), want2) < tol
 
 
 def test_instnorm_affine_fwd_bwd():
