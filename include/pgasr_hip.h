@@ -203,6 +203,20 @@ int pgasr_ctc_beam_search(const void* log_probs, int is_f64, long long stride_t,
                           int32_t* out_tokens, int32_t* out_len, double* out_score,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Elementwise pieces of the train step.
+ * pgasr_dropout: inverted dropout y = keep ? x/(1-p) : 0 (nn.Dropout, model.py:45,51 p=0.5; LSTM
+ *   inter-layer dropout model.py:42 p=0.3).  keep is a pure function of (seed, offset, element
+ *   index) (Philox4x32-10 on counter (index/4, offset), word index%4 >= p*2^32), so the backward
+ *   pass re-applies the SAME call to the gradient instead of storing a mask.  x == y allowed.
+ * pgasr_adam_step: torch.optim.Adam update (model.py:207, lr=5e-4) on flat fp32 buffers;
+ *   step is the 1-based step count used for bias correction.
+ * ---------------------------------------------------------------------------------------- */
+int pgasr_dropout(const float* x, float* y, unsigned long long n, float p, uint64_t seed, uint32_t offset,
+                  void* stream);
+int pgasr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, unsigned long long n,
+                    int step, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

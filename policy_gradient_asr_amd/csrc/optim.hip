@@ -1,0 +1,105 @@
+// Elementwise pieces of the train step for gfx950: inverted dropout with a counter-based mask
+// (nn.Dropout of model.py:45,51 and the inter-layer LSTM dropout of model.py:42) and Adam on the
+// flat parameter buffer (optim.Adam(lr=5e-4), model.py:207).  HBM-bound streaming kernels:
+// 16 B per lane, grid-stride.
+#include "common.h"
+
+namespace {
+
+// keep-mask for 4 consecutive elements from one Philox4x32-10 call:
+// counter = (quad index lo, quad index hi, offset, 0), key = seed
+__device__ __forceinline__ void keep4(unsigned long long quad, uint32_t offset, uint32_t k0, uint32_t k1,
+                                      uint32_t thresh, bool keep[4]) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)quad, (uint32_t)(quad >> 32), offset, 0u, k0, k1, r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) keep[i] = r[i] >= thresh;   // P(drop) = thresh / 2^32
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      unsigned long long n, uint32_t thresh, float scale,
+                                                      uint32_t k0, uint32_t k1, uint32_t offset) {
+    const unsigned long long nq = (n + 3) / 4;
+    for (unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x; q < nq;
+         q += (unsigned long long)gridDim.x * 256) {
+        bool keep[4];
+        keep4(q, offset, k0, k1, thresh, keep);
+        const unsigned long long i = q * 4;
+        if (i + 4 <= n) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            float4 o;
+            o.x = keep[0] ? v.x * scale : 0.f; o.y = keep[1] ? v.y * scale : 0.f;
+            o.z = keep[2] ? v.z * scale : 0.f; o.w = keep[3] ? v.w * scale : 0.f;
+            *reinterpret_cast<float4*>(y + i) = o;
+        } else {
+            for (int k = 0; k < 4 && i + k < n; ++k) y[i + k] = keep[k] ? x[i + k] * scale : 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, unsigned long long n,
+                                                   float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
+                                                   float weight_decay) {
+    // torch.optim.Adam semantics: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+    // p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+    const float step = lr / bc1;
+    for (unsigned long long i = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n;
+         i += (unsigned long long)gridDim.x * 256 * 4) {
+        if (i + 4 <= n) {
+            float4 pp = *reinterpret_cast<float4*>(p + i);
+            const float4 gg = *reinterpret_cast<const float4*>(g + i);
+            float4 mm = *reinterpret_cast<float4*>(m + i);
+            float4 vv = *reinterpret_cast<float4*>(v + i);
+            float* P = &pp.x; const float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gk = G[k] + weight_decay * P[k];
+                M[k] = beta1 * M[k] + (1.f - beta1) * gk;
+                V[k] = beta2 * V[k] + (1.f - beta2) * gk * gk;
+                P[k] -= step * M[k] / (sqrtf(V[k]) / bc2_sqrt + eps);
+            }
+            *reinterpret_cast<float4*>(p + i) = pp;
+            *reinterpret_cast<float4*>(m + i) = mm;
+            *reinterpret_cast<float4*>(v + i) = vv;
+        } else {
+            for (unsigned long long k = i; k < n; ++k) {
+                const float gk = g[k] + weight_decay * p[k];
+                m[k] = beta1 * m[k] + (1.f - beta1) * gk;
+                v[k] = beta2 * v[k] + (1.f - beta2) * gk * gk;
+                p[k] -= step * m[k] / (sqrtf(v[k]) / bc2_sqrt + eps);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int pgasr_dropout(const float* x, float* y, unsigned long long n, float p, uint64_t seed, uint32_t offset,
+                             void* stream) {
+    if (!x || !y || n == 0 || !(p >= 0.f) || !(p < 1.f)) return PGASR_ERR_INVALID_ARG;
+    if ((((size_t)x) | ((size_t)y)) & 15) return PGASR_ERR_INVALID_ARG;
+    const uint32_t thresh = (uint32_t)fmin(4294967295.0, (double)p * 4294967296.0);
+    const unsigned long long nq = (n + 3) / 4;
+    unsigned blocks = (unsigned)((nq + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, n, thresh,
+                       1.f / (1.f - p), (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), offset);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
+
+extern "C" int pgasr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, unsigned long long n,
+                               int step, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n == 0 || step < 1) return PGASR_ERR_INVALID_ARG;
+    if ((((size_t)param) | ((size_t)grad) | ((size_t)exp_avg) | ((size_t)exp_avg_sq)) & 15) return PGASR_ERR_INVALID_ARG;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    unsigned blocks = (unsigned)((n / 4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+                       lr, beta1, beta2, eps, bc1, bc2_sqrt, weight_decay);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}

@@ -16,6 +16,26 @@ def _pick_splitk(M, N, K, target_wgs=256):
     return max(sk, 1)
 
 
+class grad_overlap:
+    """Opt-in (used by train_step): run the weight-gradient GEMMs of a BLSTM layer on a side stream,
+    concurrently with the next layer's backward sweep (which only needs dX), and accumulate them
+    straight into the parameters' pre-allocated .grad buffers.  ``finish()`` makes the current
+    stream wait for the side stream; call it after loss.backward()."""
+    enabled = False
+    _side = None
+
+    @classmethod
+    def side_stream(cls):
+        if cls._side is None:
+            cls._side = torch.cuda.Stream()
+        return cls._side
+
+    @classmethod
+    def finish(cls):
+        if cls._side is not None:
+            torch.cuda.current_stream().wait_stream(cls._side)
+
+
 class InstNormAffineFn(torch.autograd.Function):
     """model.py:48-50: InstanceNorm2d over the (F,T) plane -> Linear(F,512) -> leaky_relu.
     x (B,F,T) -> y (T,B,N).  The normalisation is applied while the GEMM loads its tile."""
@@ -58,6 +78,21 @@ class InstNormAffineFn(torch.autograd.Function):
         db = torch.empty(N, dtype=torch.float32, device=x.device)
         hipops.colsum(dpre, T * B, N, N, db)
         return dW, db
+
+
+class DropoutFn(torch.autograd.Function):
+    """Inverted dropout whose mask is a pure function of (seed, offset, index): backward re-applies
+    the same kernel call to the gradient (no stored mask)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, offset):
+        ctx.cfg = (float(p), int(seed), int(offset))
+        return hipops.dropout(x.contiguous(), p, seed, offset)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, offset = ctx.cfg
+        return hipops.dropout(dy.contiguous(), p, seed, offset), None, None, None
 
 
 class LinearFn(torch.autograd.Function):
@@ -122,6 +157,7 @@ class BLSTMLayerFn(torch.autograd.Function):
         hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B)
         ctx.save_for_backward(x, lengths, gates, out, cbuf, wih_perm, pack_b, dact_y if dact_y is not None else x.new_empty(0))
         ctx.has_dact = dact_y is not None
+        ctx.param_refs = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
         return out
 
     @staticmethod
@@ -138,22 +174,38 @@ class BLSTMLayerFn(torch.autograd.Function):
             dx = torch.empty(T, B, I, dtype=torch.float32, device=dev)
             hipops.gemm(dg, wih_perm, dx, M=T * B, N=I, K=G, dact_y=dact_y if ctx.has_dact else None,
                         slope=LEAKY_SLOPE)
-        dwih = torch.empty(G, I, dtype=torch.float32, device=dev)
-        hipops.gemm(dg, x, dwih, M=G, N=I, K=T * B, transA=True, lda=G, splitk=_pick_splitk(G, I, T * B))
-        dbias = torch.empty(G, dtype=torch.float32, device=dev)
-        hipops.colsum(dg, T * B, G, G, dbias)
-        dwhh = torch.zeros(2, 4 * HID, HID, dtype=torch.float32, device=dev)
-        if T > 1:
-            # dW_hh[d] = sum_t dgates_t[d]^T h_{prev(t)}[d];  prev = t-1 (fwd) / t+1 (rev); one launch, 2 batches
-            K = (T - 1) * B
-            hipops.gemm(dg, out, dwhh, M=4 * HID, N=HID, K=K, transA=True, lda=G, ldb=2 * HID, ldc=HID,
-                        a_off=B * G, b_off=0, strideA=4 * HID - B * G, strideB=B * 2 * HID + HID,
-                        strideC=4 * HID * HID, batch=2, splitk=_pick_splitk(4 * HID, HID, K, 128))
-        gl = [torch.empty(4 * HID, I, device=dev), torch.empty(4 * HID, HID, device=dev),
-              torch.empty(4 * HID, device=dev), torch.empty(4 * HID, device=dev),
-              torch.empty(4 * HID, I, device=dev), torch.empty(4 * HID, HID, device=dev),
-              torch.empty(4 * HID, device=dev), torch.empty(4 * HID, device=dev)]
-        hipops.lstm_unpack_grads(dwih, dbias, dwhh, I, gl)
+        def weight_grads(accumulate_into=None):
+            dwih = torch.empty(G, I, dtype=torch.float32, device=dev)
+            hipops.gemm(dg, x, dwih, M=G, N=I, K=T * B, transA=True, lda=G, splitk=_pick_splitk(G, I, T * B))
+            dbias = torch.empty(G, dtype=torch.float32, device=dev)
+            hipops.colsum(dg, T * B, G, G, dbias)
+            dwhh = torch.zeros(2, 4 * HID, HID, dtype=torch.float32, device=dev)
+            if T > 1:
+                # dW_hh[d] = sum_t dgates_t[d]^T h_{prev(t)}[d];  prev = t-1 (fwd) / t+1 (rev); one launch, 2 batches
+                K = (T - 1) * B
+                hipops.gemm(dg, out, dwhh, M=4 * HID, N=HID, K=K, transA=True, lda=G, ldb=2 * HID, ldc=HID,
+                            a_off=B * G, b_off=0, strideA=4 * HID - B * G, strideB=B * 2 * HID + HID,
+                            strideC=4 * HID * HID, batch=2, splitk=_pick_splitk(4 * HID, HID, K, 128))
+            if accumulate_into is not None:
+                hipops.lstm_unpack_grads(dwih, dbias, dwhh, I, accumulate_into, accumulate=True)
+                return None
+            gl = [torch.empty(4 * HID, I, device=dev), torch.empty(4 * HID, HID, device=dev),
+                  torch.empty(4 * HID, device=dev), torch.empty(4 * HID, device=dev),
+                  torch.empty(4 * HID, I, device=dev), torch.empty(4 * HID, HID, device=dev),
+                  torch.empty(4 * HID, device=dev), torch.empty(4 * HID, device=dev)]
+            hipops.lstm_unpack_grads(dwih, dbias, dwhh, I, gl)
+            return gl
+
+        targets = [p.grad for p in ctx.param_refs]
+        if grad_overlap.enabled and all(t is not None and t.is_contiguous() for t in targets):
+            side = grad_overlap.side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                weight_grads(accumulate_into=targets)
+            for t_ in (dg, x, out):
+                t_.record_stream(side)
+            return (dx, None, None) + (None,) * 8
+        gl = weight_grads()
         return (dx, None, None, *gl)
 
 

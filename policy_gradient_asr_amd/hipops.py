@@ -313,3 +313,25 @@ def ctc_beam_search(log_probs, lengths=None, beam=5, blank=0):
                                    _p(tokens), _p(tl), _p(score), _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_ctc_beam_search")
     return tokens, tl, score
+
+
+# ------------------------------------------------------------------------------------------
+# dropout / Adam
+# ------------------------------------------------------------------------------------------
+def dropout(x, p, seed, offset, out=None):
+    lib = _lib.load()
+    _req(x, torch.float32, "x")
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.pgasr_dropout(_p(x), _p(out), x.numel(), float(p), int(seed) & (2 ** 64 - 1),
+                                 int(offset) & 0xFFFFFFFF, _stream()), "pgasr_dropout")
+    return out
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    lib = _lib.load()
+    for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(t, torch.float32, nm)
+    _lib.check(lib.pgasr_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), int(step),
+                                   float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                                   _stream()), "pgasr_adam_step")

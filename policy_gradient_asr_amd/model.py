@@ -47,6 +47,8 @@ class Encoder(nn.Module):
         self.blstm = nn.LSTM(input_size=512, hidden_size=HID, num_layers=3, dropout=0.3,
                              bidirectional=True, batch_first=True)
         self.drop = nn.Dropout()
+        self.dropout_seed = 0x5EED          # masks are functions of (seed, call counter, index)
+        self._drop_calls = 0
 
     def _layer_params(self, l):
         out = []
@@ -64,13 +66,17 @@ class Encoder(nn.Module):
         fuse = not training
         y = Fh.InstNormAffineFn.apply(x.float(), self.input_layer.weight, self.input_layer.bias, fuse)
         h = y
-        if training:
-            h = self.drop(h)
+        if training:                                   # nn.Dropout(), model.py:45,51
+            h = Fh.DropoutFn.apply(h, self.drop.p, self.dropout_seed, self._next_drop_offset())
         for l in range(3):
             h = Fh.blstm_layer(h, lengths, self._layer_params(l), dact_y=y if (l == 0 and fuse) else None)
-            if training and l < 2:
-                h = nn.functional.dropout(h, 0.3, True)
+            if training and l < 2:                     # nn.LSTM(dropout=0.3), model.py:42: outputs of layers 0,1
+                h = Fh.DropoutFn.apply(h, self.blstm.dropout, self.dropout_seed, self._next_drop_offset())
         return h, lengths
+
+    def _next_drop_offset(self):
+        self._drop_calls += 1
+        return self._drop_calls
 
     def forward(self, x, mask):
         h, _ = self.forward_time_major(x, mask)

@@ -69,7 +69,13 @@ class DataParallelStep:
         self.flat_param = torch.nn.Parameter(self.flat)
         self.flat_param.grad = self.gflat
         # Adam(lr=5e-4) is the reference's commented choice (model.py:207)
-        self.opt = torch.optim.Adam([self.flat_param], lr=lr, fused=bool(self.flat.is_cuda))
+        self.lr = lr
+        if self.flat.is_cuda:
+            self.exp_avg = torch.zeros_like(self.flat)
+            self.exp_avg_sq = torch.zeros_like(self.flat)
+            self.opt = None
+        else:   # CPU is only the gloo plumbing test: torch's Adam
+            self.opt = torch.optim.Adam([self.flat_param], lr=lr)
         self.nstep = 0
         if self.world > 1:
             dist.broadcast(self.flat, src=0, group=self.pg)   # identical replicas
@@ -77,15 +83,22 @@ class DataParallelStep:
     def forward_loss(self, batch, global_batch):  # pragma: no cover - abstract
         raise NotImplementedError
 
+    def backward(self, loss):
+        loss.backward()
+
     def step(self, *batch):
         local_b = batch[0].shape[0]
         self.gflat.zero_()
         loss = self.forward_loss(batch, local_b * self.world)
-        loss.backward()
+        self.backward(loss)
         if self.world > 1:
             dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.pg)
-        self.opt.step()
         self.nstep += 1
+        if self.opt is None:
+            from . import hipops
+            hipops.adam_step(self.flat, self.gflat, self.exp_avg, self.exp_avg_sq, self.nstep, lr=self.lr)
+        else:
+            self.opt.step()
         return loss.detach()
 
 
@@ -98,8 +111,21 @@ class PolicyGradientTrainer(DataParallelStep):
         super().__init__(model, lr=lr, world_size=world_size, process_group=process_group)
         self.lam = lam
         self.seed = seed + 7919 * rank     # independent sample streams per rank
+        if hasattr(model, "encoder"):
+            model.encoder.dropout_seed = 0x5EED + 104729 * rank
         self.blank = blank
         self.last_stats = None
+        self.overlap_weight_grads = True
+
+    def backward(self, loss):
+        """Weight-gradient GEMMs run on a side stream under the next layer's backward sweep."""
+        from .functional import grad_overlap
+        grad_overlap.enabled = self.overlap_weight_grads
+        try:
+            loss.backward()
+        finally:
+            grad_overlap.enabled = False
+            grad_overlap.finish()
 
     def forward_loss(self, batch, global_batch):
         from .loss import pg_ctc_loss
@@ -108,6 +134,6 @@ class PolicyGradientTrainer(DataParallelStep):
         tg = targets.to(torch.int32).contiguous()
         logits, in_len = self.model.logits(x, fmask)
         loss, nll, R_s, R_g = pg_ctc_loss(logits, in_len, tg, tg_len, lam=self.lam, seed=self.seed,
-                                          offset=self.nstep, global_batch=global_batch, blank=self.blank)
+                                          offset=self.nstep + 1, global_batch=global_batch, blank=self.blank)
         self.last_stats = (nll, R_s, R_g)
         return loss

@@ -140,3 +140,62 @@ def test_trainer_steps_reduce_loss():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     # parameters are views of the flat buffer
     assert m.head.weight.data_ptr() >= tr.flat.data_ptr()
+
+
+def test_dropout_kernel_mask_and_backward():
+    from policy_gradient_asr_amd import hipops, functional as Fh
+    x = torch.ones(1000, 37, device=DEV)     # odd size exercises the tail
+    y = hipops.dropout(x, 0.3, seed=99, offset=4)
+    keep = (y != 0)
+    assert abs(float(keep.float().mean()) - 0.7) < 0.01
+    assert torch.allclose(y[keep], torch.full_like(y[keep], 1 / 0.7))
+    assert torch.equal(y, hipops.dropout(x, 0.3, seed=99, offset=4))            # deterministic
+    assert not torch.equal(y, hipops.dropout(x, 0.3, seed=99, offset=5))        # new offset, new mask
+    xg = torch.randn(64, 50, device=DEV, requires_grad=True)
+    out = Fh.DropoutFn.apply(xg, 0.5, 7, 1)
+    out.backward(torch.ones_like(out))
+    assert torch.equal(xg.grad != 0, out != 0) and torch.allclose(xg.grad[out != 0], torch.tensor(2.0, device=DEV))
+    assert torch.equal(hipops.dropout(x, 0.0, 1, 1), x)
+
+
+def test_adam_kernel_matches_torch():
+    from policy_gradient_asr_amd import hipops
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(10007, generator=g); grads = [torch.randn(10007, generator=g) * 0.1 for _ in range(5)]
+    ref = torch.nn.Parameter(p0.clone()); opt = torch.optim.Adam([ref], lr=5e-4)
+    p = p0.clone().to(DEV); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    for i, gr in enumerate(grads):
+        ref.grad = gr.clone(); opt.step()
+        hipops.adam_step(p, gr.to(DEV), m, v, i + 1, lr=5e-4)
+    torch.testing.assert_close(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-7)
+
+
+def test_weight_grad_overlap_gives_identical_gradients():
+    from policy_gradient_asr_amd.model import Seq2Seq, weights
+    from policy_gradient_asr_amd.train_step import PolicyGradientTrainer
+    B, F, T, V, L = 20, 80, 60, 29, 6
+    x, targets, fmask, tmask = _make(B, F, T, V, L, [60] * 10 + [41] * 10, [6] * 20, 3)
+    grads = []
+    for ov in (False, True):
+        torch.manual_seed(0)
+        m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(DEV).eval()
+        tr = PolicyGradientTrainer(m, lr=0.0, lam=1.0, seed=5)
+        tr.overlap_weight_grads = ov
+        tr.step(x.to(DEV), targets.to(DEV), fmask.to(DEV), tmask.to(DEV))
+        torch.cuda.synchronize()
+        grads.append(tr.gflat.clone())
+    assert torch.equal(grads[0], grads[1])
+
+
+def test_train_mode_step_runs_with_dropout():
+    from policy_gradient_asr_amd.model import Seq2Seq, weights
+    from policy_gradient_asr_amd.train_step import PolicyGradientTrainer
+    torch.manual_seed(0)
+    B, F, T, V, L = 4, 80, 50, 29, 5
+    x, targets, fmask, tmask = _make(B, F, T, V, L, [50] * 4, [5] * 4, 2)
+    m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(DEV).train()
+    tr = PolicyGradientTrainer(m, lr=1e-3, lam=0.0, seed=1)
+    l0 = float(tr.step(x.to(DEV), targets.to(DEV), fmask.to(DEV), tmask.to(DEV)))
+    for _ in range(15):
+        l1 = float(tr.step(x.to(DEV), targets.to(DEV), fmask.to(DEV), tmask.to(DEV)))
+    assert np.isfinite(l1) and l1 < l0

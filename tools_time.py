@@ -40,3 +40,15 @@ y.backward(dy.float().to(dev)); torch.cuda.synchronize()
 re = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())
 print(f"precision: out {re(y.detach(), o.detach()):.2e}  dx {re(xg.grad, xr.grad):.2e}  " +
       "  ".join(f"{n_[7:]} {re(p_.grad, getattr(lstm, n_).grad):.2e}" for n_, p_ in zip(names, ps)), flush=True)
+
+# ---- A/B: weight-gradient overlap on/off (interleaved) ----
+import time
+for rnd in range(2):
+    for ov in (False, True):
+        tr.overlap_weight_grads = ov
+        tr.step(*batch); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(5):
+            tr.step(*batch)
+        torch.cuda.synchronize()
+        print(f"overlap={ov}: {(time.perf_counter()-t0)*1e3/5:.2f} ms/step", flush=True)
