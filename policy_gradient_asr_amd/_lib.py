@@ -6,6 +6,12 @@ status this module raises.  Nothing here imports ``oracle``.
 import ctypes as C
 import os
 
+# Import order matters: PyTorch bundles its own HIP runtime (torch/lib/libamdhip64.so).  Loading this
+# library first would pull in the system ROCm runtime as well, and kernels launched through one
+# runtime on memory/streams owned by the other fail.  With torch loaded first the library's
+# libamdhip64.so.7 dependency resolves to the runtime torch already mapped: ONE runtime per process.
+import torch  # noqa: F401  (must precede CDLL below)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PGASR_HIP_LIB", os.path.join(_HERE, "libpgasr_hip.so"))   # override: diagnostic builds
 

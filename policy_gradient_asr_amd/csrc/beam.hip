@@ -275,11 +275,11 @@ extern "C" int pgasr_ctc_beam_search(const void* log_probs, int is_f64, long lon
     if (lds > 160 * 1024) return PGASR_ERR_UNSUPPORTED;
     if (is_f64) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&beam_search_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(beam_search_kernel<double>, dim3(B), dim3(BEAM_THREADS), lds, st, (const double*)log_probs,
+        PGASR_LAUNCH_KERNEL(beam_search_kernel<double>, dim3(B), dim3(BEAM_THREADS), lds, st, (const double*)log_probs,
                            stride_t, stride_b, lengths, T, V, beam, blank, ws, out_tokens, out_len, out_score);
     } else {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&beam_search_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(beam_search_kernel<float>, dim3(B), dim3(BEAM_THREADS), lds, st, (const float*)log_probs,
+        PGASR_LAUNCH_KERNEL(beam_search_kernel<float>, dim3(B), dim3(BEAM_THREADS), lds, st, (const float*)log_probs,
                            stride_t, stride_b, lengths, T, V, beam, blank, ws, out_tokens, out_len, out_score);
     }
     PGASR_CHECK_LAUNCH();

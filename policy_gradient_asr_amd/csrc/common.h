@@ -3,14 +3,29 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "pgasr_hip.h"
 
 #define PGASR_WAVE 64
 
-#define PGASR_CHECK_LAUNCH()                                   \
+// hipGetLastError() is sticky per thread: clear whatever an earlier, unrelated runtime call left
+// behind (e.g. PyTorch's start-up probes) before a launch, so the check after it reports THIS launch.
+#define PGASR_LAUNCH_KERNEL(...)                               \
     do {                                                       \
-        hipError_t e__ = hipGetLastError();                    \
-        if (e__ != hipSuccess) return PGASR_ERR_LAUNCH;        \
+        (void)hipGetLastError();                               \
+        hipLaunchKernelGGL(__VA_ARGS__);                       \
+    } while (0)
+
+#define PGASR_CHECK_LAUNCH()                                                                  \
+    do {                                                                                      \
+        hipError_t e__ = hipGetLastError();                                                   \
+        if (e__ != hipSuccess) {                                                              \
+            if (getenv("PGASR_DEBUG"))                                                        \
+                fprintf(stderr, "[pgasr] %s:%d launch failed: %s\n", __FILE__, __LINE__,      \
+                        hipGetErrorString(e__));                                              \
+            return PGASR_ERR_LAUNCH;                                                          \
+        }                                                                                     \
     } while (0)
 
 static inline size_t pgasr_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

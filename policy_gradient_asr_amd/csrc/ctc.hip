@@ -266,7 +266,7 @@ extern "C" int pgasr_ctc_loss_grad(const float* log_probs, const int32_t* target
     if (!workspace || workspace_bytes < need) return PGASR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     // Lmax == 0 still needs a valid targets row pointer; Lmax>=1 is the caller's job.
-    hipLaunchKernelGGL(ctc_lattice_kernel, dim3(B, 3), dim3(CTC_THREADS), 0, st,
+    PGASR_LAUNCH_KERNEL(ctc_lattice_kernel, dim3(B, 3), dim3(CTC_THREADS), 0, st,
                        log_probs, targets, input_lengths, target_lengths, T, B, V,
                        Lmax > 0 ? Lmax : 1, Smax, blank, ws, nll);
     PGASR_CHECK_LAUNCH();
@@ -274,7 +274,7 @@ extern "C" int pgasr_ctc_loss_grad(const float* log_probs, const int32_t* target
         const long long waves = (long long)T * B;
         const int wpb = 4;
         const unsigned blocks = (unsigned)((waves + wpb - 1) / wpb);
-        hipLaunchKernelGGL(ctc_grad_kernel, dim3(blocks), dim3(64 * wpb), 0, st,
+        PGASR_LAUNCH_KERNEL(ctc_grad_kernel, dim3(blocks), dim3(64 * wpb), 0, st,
                            log_probs, input_lengths, target_lengths, T, B, V,
                            Lmax > 0 ? Lmax : 1, Smax, blank, ws, utt_scale, pg_coef, pg_path, grad_logits);
         PGASR_CHECK_LAUNCH();

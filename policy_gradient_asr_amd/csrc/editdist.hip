@@ -98,7 +98,7 @@ extern "C" int pgasr_edit_distance(const int32_t* ref, const int32_t* ref_len, i
     const int need = (ref_stride + 1 + 63) / 64;  // cells per lane
     hipStream_t st = (hipStream_t)stream;
 #define ED_LAUNCH(JJ)                                                                             \
-    hipLaunchKernelGGL(edit_distance_kernel<JJ>, dim3(N), dim3(64), 0, st, ref, ref_len,          \
+    PGASR_LAUNCH_KERNEL(edit_distance_kernel<JJ>, dim3(N), dim3(64), 0, st, ref, ref_len,          \
                        ref_stride, hyp, hyp_len, hyp_stride, dist, prefix_dist)
     if (need <= 1) ED_LAUNCH(1);
     else if (need <= 2) ED_LAUNCH(2);

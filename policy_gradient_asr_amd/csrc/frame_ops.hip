@@ -122,7 +122,7 @@ extern "C" int pgasr_log_softmax_rows(const float* logits, long long rows, int V
     if (!logits || !log_probs || rows <= 0 || V <= 0) return PGASR_ERR_INVALID_ARG;
     if (V > 64) return PGASR_ERR_UNSUPPORTED;
     const unsigned blocks = (unsigned)((rows + 3) / 4);
-    hipLaunchKernelGGL(log_softmax_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, rows, V, log_probs);
+    PGASR_LAUNCH_KERNEL(log_softmax_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, rows, V, log_probs);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }
@@ -135,7 +135,7 @@ extern "C" int pgasr_frame_argmax_sample(const float* scores, int T, int B, int 
     if (!greedy_path && !sample_path) return PGASR_OK;
     const long long rows = (long long)T * B;
     const unsigned blocks = (unsigned)((rows + 3) / 4);
-    hipLaunchKernelGGL(frame_argmax_sample_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+    PGASR_LAUNCH_KERNEL(frame_argmax_sample_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        scores, rows, B, V, (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), offset,
                        greedy_path, sample_path);
     PGASR_CHECK_LAUNCH();
@@ -145,7 +145,7 @@ extern "C" int pgasr_frame_argmax_sample(const float* scores, int T, int B, int 
 extern "C" int pgasr_ctc_collapse(const int32_t* paths, const int32_t* lengths, int P, int T, int B,
                                   int blank, int32_t* tokens, int32_t* token_lengths, void* stream) {
     if (!paths || !tokens || !token_lengths || P <= 0 || T <= 0 || B <= 0) return PGASR_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B, P), dim3(256), 0, (hipStream_t)stream,
+    PGASR_LAUNCH_KERNEL(ctc_collapse_kernel, dim3(B, P), dim3(256), 0, (hipStream_t)stream,
                        paths, lengths, T, B, blank, tokens, token_lengths);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
@@ -158,7 +158,7 @@ extern "C" int pgasr_reinforce_grad(const float* scores, const int32_t* path, co
     if (V > 64) return PGASR_ERR_UNSUPPORTED;
     const long long rows = (long long)T * B;
     const unsigned blocks = (unsigned)((rows + 3) / 4);
-    hipLaunchKernelGGL(reinforce_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+    PGASR_LAUNCH_KERNEL(reinforce_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        scores, path, coef, lengths, rows, B, V, accumulate, grad);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;

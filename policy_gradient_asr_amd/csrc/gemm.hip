@@ -497,20 +497,20 @@ static int gemm_launch(GemmArgs& g, int transA, int transB, int sum_batches, int
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, Z);
     if (grid.y > 65535 || grid.z > 65535) return PGASR_ERR_UNSUPPORTED;
     if (precision == 1) {
-        if (!transA && !transB) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, dim3(GEMM_THREADS), 0, st, g);
-        else if (!transA && transB) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true>), grid, dim3(GEMM_THREADS), 0, st, g);
-        else if (transA && !transB) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), grid, dim3(GEMM_THREADS), 0, st, g);
-        else hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, st, g);
+        if (!transA && !transB) PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<false, false>), grid, dim3(GEMM_THREADS), 0, st, g);
+        else if (!transA && transB) PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<false, true>), grid, dim3(GEMM_THREADS), 0, st, g);
+        else if (transA && !transB) PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<true, false>), grid, dim3(GEMM_THREADS), 0, st, g);
+        else PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, st, g);
     }
-    else if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(GEMM_THREADS), 0, st, g);
-    else if (!transA && transB) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(GEMM_THREADS), 0, st, g);
-    else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(GEMM_THREADS), 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, st, g);
+    else if (!transA && !transB) PGASR_LAUNCH_KERNEL((gemm_f32_kernel<false, false>), grid, dim3(GEMM_THREADS), 0, st, g);
+    else if (!transA && transB) PGASR_LAUNCH_KERNEL((gemm_f32_kernel<false, true>), grid, dim3(GEMM_THREADS), 0, st, g);
+    else if (transA && !transB) PGASR_LAUNCH_KERNEL((gemm_f32_kernel<true, false>), grid, dim3(GEMM_THREADS), 0, st, g);
+    else PGASR_LAUNCH_KERNEL((gemm_f32_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, st, g);
     PGASR_CHECK_LAUNCH();
     if (use_partial) {
         const size_t total = (size_t)g.M * g.N;
         const int nout = sum_batches ? 1 : g.batch;
-        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((total + 255) / 256), nout), dim3(256), 0, st,
+        PGASR_LAUNCH_KERNEL(gemm_reduce_kernel, dim3((unsigned)((total + 255) / 256), nout), dim3(256), 0, st,
                            g.partial, Z / nout, g.M, g.N, g.C, g.ldc, g.sC, g.bias, g.bias2, g.act, g.slope,
                            g.accumulate);
         PGASR_CHECK_LAUNCH();
@@ -562,10 +562,10 @@ extern "C" int pgasr_colsum_f32(const float* X, int rows, int cols, int ld, floa
     const int nparts = (rows + rpb - 1) / rpb;
     if (!workspace || workspace_bytes < (size_t)nparts * cols * sizeof(float)) return PGASR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, nparts), dim3(256), 0, st, X, rows, cols, ld, rpb,
+    PGASR_LAUNCH_KERNEL(colsum_partial_kernel, dim3((cols + 63) / 64, nparts), dim3(256), 0, st, X, rows, cols, ld, rpb,
                        (float*)workspace);
     PGASR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, (const float*)workspace, nparts,
+    PGASR_LAUNCH_KERNEL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, (const float*)workspace, nparts,
                        cols, out, out2, accumulate);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
@@ -574,7 +574,7 @@ extern "C" int pgasr_colsum_f32(const float* X, int rows, int cols, int ld, floa
 extern "C" int pgasr_instnorm_stats(const float* x, int B, int F, int T, float eps, float* mean, float* rstd,
                                     void* stream) {
     if (!x || !mean || !rstd || B <= 0 || F <= 0 || T <= 0) return PGASR_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(instnorm_stats_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, (long long)F * T, eps,
+    PGASR_LAUNCH_KERNEL(instnorm_stats_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, (long long)F * T, eps,
                        mean, rstd);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;

@@ -581,7 +581,7 @@ extern "C" int pgasr_lstm_pack_weights(const float* w_ih_f, const float* w_hh_f,
     p.wpf = (unsigned short*)whh_pack_fwd; p.wpb = (unsigned short*)whh_pack_bwd;
     const size_t n_wih = (size_t)2 * 4 * HID * in_dim, n_pack = (size_t)2 * 64 * 8 * 64 * 8;
     const size_t n = n_wih > n_pack ? n_wih : n_pack;
-    hipLaunchKernelGGL(lstm_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    PGASR_LAUNCH_KERNEL(lstm_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }
@@ -599,7 +599,7 @@ extern "C" int pgasr_lstm_unpack_grads(const float* dwih_perm, const float* dbia
     u.in_dim = in_dim; u.accumulate = accumulate;
     const size_t n_wih = (size_t)2 * 4 * HID * in_dim, n_whh = (size_t)2 * 4 * HID * HID;
     const size_t n = n_wih > n_whh ? n_wih : n_whh;
-    hipLaunchKernelGGL(lstm_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u);
+    PGASR_LAUNCH_KERNEL(lstm_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }
@@ -631,8 +631,8 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
     if (T > STAMP_MAX_T) return PGASR_ERR_UNSUPPORTED;
 #endif
     dim3 grid(G_CLUSTER * l.NCL8);
-    if (backward) hipLaunchKernelGGL(lstm_bwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
-    else hipLaunchKernelGGL(lstm_fwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
+    if (backward) PGASR_LAUNCH_KERNEL(lstm_bwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
+    else PGASR_LAUNCH_KERNEL(lstm_fwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }

@@ -83,7 +83,7 @@ extern "C" int pgasr_dropout(const float* x, float* y, unsigned long long n, flo
     const unsigned long long nq = (n + 3) / 4;
     unsigned blocks = (unsigned)((nq + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, n, thresh,
+    PGASR_LAUNCH_KERNEL(dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, n, thresh,
                        1.f / (1.f - p), (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), offset);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
@@ -98,7 +98,7 @@ extern "C" int pgasr_adam_step(float* param, const float* grad, float* exp_avg, 
     unsigned blocks = (unsigned)((n / 4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+    PGASR_LAUNCH_KERNEL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
                        lr, beta1, beta2, eps, bc1, bc2_sqrt, weight_decay);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
