@@ -91,7 +91,7 @@ int pgasr_ctc_collapse(const int32_t* paths, const int32_t* lengths, int P, int 
  *   ref (N,ref_stride) int32 with ref_len (N); hyp (N,hyp_stride) int32 with hyp_len (N);
  *   dist[n] = ED(ref_n, hyp_n).  If prefix_dist != NULL it is (N,hyp_stride+1) and receives
  *   ED(ref_n, hyp_n[:i]) for i = 0..hyp_len[n] -- the quantity policy_grad.py:11-15
- *   differences to form r_t.  Limit: ref_len <= 4095.
+ *   differences to form r_t.  Limit: sequence lengths <= 4095.
  * ---------------------------------------------------------------------------------------- */
 int pgasr_edit_distance(const int32_t* ref, const int32_t* ref_len, int ref_stride,
                         const int32_t* hyp, const int32_t* hyp_len, int hyp_stride,

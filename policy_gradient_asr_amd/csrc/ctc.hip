@@ -58,9 +58,9 @@ __device__ __forceinline__ double lse3(double a0, double a1, double a2) {
 __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(
     const float* __restrict__ lp, const int32_t* __restrict__ targets,
     const int32_t* __restrict__ in_len, const int32_t* __restrict__ tg_len,
-    int T, int B, int V, int Lmax, int Smax, int blank, CtcWs ws, float* __restrict__ nll_out) {
+    int T, int B, int V, int Lmax, int Smax, int blank, CtcWs ws, float* __restrict__ nll_out, int role_base) {
     const int b = blockIdx.x;
-    const int role = blockIdx.y;
+    const int role = blockIdx.y + role_base;
     const int tid = threadIdx.x;
     int Tb = in_len[b]; Tb = Tb < 0 ? 0 : (Tb > T ? T : Tb);
     int Lb = tg_len[b]; Lb = Lb < 0 ? 0 : (Lb > Lmax ? Lmax : Lb);
@@ -193,6 +193,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(
     }
 }
 
+
 // one wave per (t,b)
 __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const float* __restrict__ lp, const int32_t* __restrict__ in_len, const int32_t* __restrict__ tg_len,
@@ -266,9 +267,11 @@ extern "C" int pgasr_ctc_loss_grad(const float* log_probs, const int32_t* target
     if (!workspace || workspace_bytes < need) return PGASR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     // Lmax == 0 still needs a valid targets row pointer; Lmax>=1 is the caller's job.
+    // (a single-wave register-resident variant was measured SLOWER: 850 us vs 492 us at S=201 --
+    // one wave's fp64 VALU issue rate, not the barrier, is then the limit)
     PGASR_LAUNCH_KERNEL(ctc_lattice_kernel, dim3(B, 3), dim3(CTC_THREADS), 0, st,
-                       log_probs, targets, input_lengths, target_lengths, T, B, V,
-                       Lmax > 0 ? Lmax : 1, Smax, blank, ws, nll);
+                        log_probs, targets, input_lengths, target_lengths, T, B, V,
+                        Lmax > 0 ? Lmax : 1, Smax, blank, ws, nll, 0);
     PGASR_CHECK_LAUNCH();
     if (grad_logits) {
         const long long waves = (long long)T * B;

@@ -25,6 +25,10 @@ __global__ __launch_bounds__(64) void edit_distance_kernel(
     const int32_t* r = ref + (size_t)n_pair * ref_stride;
     const int32_t* h = hyp + (size_t)n_pair * hyp_stride;
     int32_t* pd = prefix_dist ? prefix_dist + (size_t)n_pair * (hyp_stride + 1) : nullptr;
+    // The distance is symmetric, and the rows are the serial chain: unless per-prefix distances
+    // of the hypothesis are requested, iterate over the SHORTER sequence and keep the longer one
+    // across the lanes (an untrained model emits ~T tokens against ~T/10 reference labels).
+    if (!pd && m > n) { const int32_t* tp = r; r = h; h = tp; const int tn = n; n = m; m = tn; }
 
     const int j0 = lane * J;
     int rt[J];    // ref token left of cell j (ref[j-1]); unused for j == 0 or j > n
@@ -94,8 +98,9 @@ extern "C" int pgasr_edit_distance(const int32_t* ref, const int32_t* ref_len, i
                                    int N, int32_t* dist, int32_t* prefix_dist, void* stream) {
     if (!ref_len || !hyp_len || !dist || N <= 0 || ref_stride < 0 || hyp_stride < 0) return PGASR_ERR_INVALID_ARG;
     if ((ref_stride > 0 && !ref) || (hyp_stride > 0 && !hyp)) return PGASR_ERR_INVALID_ARG;
-    if (ref_stride > 4095) return PGASR_ERR_UNSUPPORTED;
-    const int need = (ref_stride + 1 + 63) / 64;  // cells per lane
+    const int col_max = prefix_dist ? ref_stride : (ref_stride > hyp_stride ? ref_stride : hyp_stride);
+    if (col_max > 4095) return PGASR_ERR_UNSUPPORTED;
+    const int need = (col_max + 1 + 63) / 64;  // cells per lane
     hipStream_t st = (hipStream_t)stream;
 #define ED_LAUNCH(JJ)                                                                             \
     PGASR_LAUNCH_KERNEL(edit_distance_kernel<JJ>, dim3(N), dim3(64), 0, st, ref, ref_len,          \
