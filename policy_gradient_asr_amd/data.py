@@ -1,0 +1,105 @@
+"""Batch format of the reference's data.py (row A0 of SURVEY §8a) -- host-side only.
+
+``collate_custom`` returns the reference's batch dict {"feat" (B,F,Tmax) fp32 zero padded,
+"fmask" (B,1,Tmax), "trans" (B,Lmax) int64 pad 0, "tmask" (B,Lmax)} (data.py:107-116).  Feature
+extraction (``extract_feats``, data.py:44-79: MFCC(40)+delta+delta-delta via torchaudio) is out of
+scope of the hot path; it is kept as a torchaudio-gated function so the driver shells run
+wherever torchaudio exists, and ``SyntheticSpeech`` supplies ready-made features otherwise."""
+import os
+
+import torch
+import torch.nn as nn
+import torch.utils.data as data
+
+
+def pad_feats(feats):
+    """list of (F,T_i) tensors -> (B,F,Tmax) zero padded, (B,1,Tmax) masks (data.py:64-79)."""
+    tmax = max(f.shape[1] for f in feats)
+    padded, masks = [], []
+    for f in feats:
+        mask = torch.ones(1, f.shape[1])
+        padded.append(nn.functional.pad(f, (0, tmax - f.shape[1], 0, 0)))
+        masks.append(nn.functional.pad(mask, (0, tmax - f.shape[1], 0, 0)))
+    return torch.stack(padded), torch.stack(masks)
+
+
+def extract_feats(batch):
+    """MFCC + deltas as data.py:44-62 (needs torchaudio) or precomputed "feat" entries."""
+    feats = []
+    for inst in batch:
+        if "feat" in inst:
+            feats.append(inst["feat"])
+            continue
+        try:
+            import torchaudio
+        except ImportError as e:  # pragma: no cover - torchaudio absent in this image
+            raise ImportError("feature extraction (data.py:44-62) needs torchaudio; pass precomputed 'feat'") from e
+        waveform, _sr = torchaudio.load(inst["aud"])
+        mfcc = torchaudio.transforms.MFCC()(waveform)
+        d1 = torchaudio.transforms.ComputeDeltas()(mfcc)
+        d2 = torchaudio.transforms.ComputeDeltas()(d1)
+        feats.append(torch.cat((mfcc, d1, d2), dim=1).squeeze(0))
+    return pad_feats(feats)
+
+
+def encode_trans(batch):
+    """char -> index with pad 0, mask = (id > 0) (data.py:82-104)."""
+    char2ind = batch[0]["charmap"]
+    enc = [torch.tensor([char2ind[c] for c in inst["trans"]], dtype=torch.int64) for inst in batch]
+    lmax = max(max((e.shape[0] for e in enc), default=1), 1)
+    out = torch.stack([nn.functional.pad(e, (0, lmax - e.shape[0])) for e in enc])
+    return out, (out > 0).to(torch.int64)
+
+
+def collate_custom(batch):
+    feats, fmasks = extract_feats(batch)
+    trans, tmasks = encode_trans(batch)
+    return {"feat": feats, "fmask": fmasks, "trans": trans, "tmask": tmasks}
+
+
+class Data(data.Dataset):
+    """Data(csv_path, aud_path, char2ind) (data.py:118-132): CommonVoice TSV rows."""
+
+    def __init__(self, csv_path, aud_path, char2ind):
+        import pandas as pd
+        self.df = pd.read_csv(csv_path, sep="\t")
+        self.char2ind = char2ind
+        self.fnames = [os.path.join(aud_path, f) for f in self.df["path"]]
+        self.transcrpts = self.df["sentence"]
+
+    def __len__(self):
+        return len(self.df)
+
+    def __getitem__(self, idx):
+        if torch.is_tensor(idx):
+            idx = idx.tolist()
+        return {"aud": self.fnames[idx], "trans": self.transcrpts[idx], "charmap": self.char2ind}
+
+
+class SyntheticSpeech(data.Dataset):
+    """Seeded stand-in corpus: each item carries a precomputed (F,T_i) feature matrix whose frames
+    are noisy one-hot-ish codes of its transcript (learnable by CTC), so the driver shells can be
+    exercised without audio files."""
+
+    def __init__(self, n_items, char2ind, n_feats=80, max_chars=8, frames_per_char=6, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.char2ind = char2ind
+        chars = [c for c, i in char2ind.items() if i > 0]
+        proto = torch.randn(len(char2ind), n_feats, generator=g)
+        self.items = []
+        for _ in range(n_items):
+            n = int(torch.randint(2, max_chars + 1, (1,), generator=g))
+            text = "".join(chars[int(torch.randint(0, len(chars), (1,), generator=g))] for _ in range(n))
+            frames = []
+            for ch in text:
+                k = int(torch.randint(frames_per_char - 2, frames_per_char + 3, (1,), generator=g))
+                frames.append(proto[char2ind[ch]].unsqueeze(1).repeat(1, k))
+            feat = torch.cat(frames, dim=1)
+            feat = feat + 0.3 * torch.randn(feat.shape, generator=g)
+            self.items.append({"feat": feat, "trans": text, "charmap": char2ind})
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, idx):
+        return self.items[idx]

@@ -121,3 +121,141 @@ class Seq2Seq(nn.Module):
     def forward(self, x, t, fmask, device=None):
         z, _ = self.logits(x, fmask)
         return Fh.LogSoftmaxFn.apply(z)
+
+
+# ------------------------------------------------------------------------------------------
+# driver shells: same positional signatures as model.py:186 / :277
+# ------------------------------------------------------------------------------------------
+def _read_alphabet(alphabet_path):
+    with open(alphabet_path, "r") as fo:
+        alphabet = ["<pad>"] + fo.readlines()                       # model.py:194-195
+    char2ind = {alphabet[i].replace("\n", ""): i for i in range(len(alphabet))}   # model.py:197
+    return alphabet, char2ind
+
+
+def _to_device(batch, device):
+    x = batch["feat"].to(device)                                    # model.py:227-230
+    t = batch["trans"].to(device)
+    fmask = batch["fmask"].squeeze(1).to(device)
+    tmask = batch["tmask"].squeeze(1).to(device)
+    return x, t, fmask, tmask
+
+
+def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset=None, dev_dataset=None,
+          n_feats=120, lam=1.0, lr=5e-4, resume=True, log_every=10, seed=0):
+    """Epoch loop of model.py:186-274 on the MI355X path: per-epoch train loss -> train_loss.npy,
+    validation CTC loss -> val_losses.npy, model_best.pth / model_last.pth (state_dicts, reference
+    names), plus checkpoint_last.pth (model + Adam moments + epoch) from which ``resume`` restarts
+    -- the reference saves weights only.  ``train_dataset`` / ``dev_dataset`` default to the
+    reference's Data(train.tsv / dev.tsv, clips) and accept any Dataset of collate_custom items."""
+    import os
+    import numpy as np
+    import torch.utils.data as tud
+    from .data import Data, collate_custom
+    from .loss import pg_ctc_loss
+    from .train_step import PolicyGradientTrainer
+
+    print("Num epochs:", num_epochs, "Batch size:", batch_size)
+    alphabet, char2ind = _read_alphabet(os.path.join(corpus_path, "alphabet.txt"))
+    dev = torch.device("cuda", device if isinstance(device, int) else 0) if not isinstance(device, torch.device) else device
+    os.makedirs(model_path, exist_ok=True)
+    if train_dataset is None:
+        train_dataset = Data(os.path.join(corpus_path, "train.tsv"), os.path.join(corpus_path, "clips"), char2ind)
+    if dev_dataset is None and os.path.exists(os.path.join(corpus_path, "dev.tsv")):
+        dev_dataset = Data(os.path.join(corpus_path, "dev.tsv"), os.path.join(corpus_path, "clips"), char2ind)
+
+    torch.manual_seed(seed)
+    model = Seq2Seq(alphabet_size=len(char2ind), n_feats=n_feats)
+    model.apply(weights)                                            # model.py:202
+    model = model.to(dev)
+    trainer = PolicyGradientTrainer(model, lr=lr, lam=lam, seed=seed)
+    losses, val_losses, best, start_epoch = [], [], 9999999.0, 1
+    ckpt = os.path.join(model_path, "checkpoint_last.pth")
+    if resume and os.path.exists(ckpt):
+        st = torch.load(ckpt, map_location=dev)
+        model.load_state_dict(st["model"])
+        trainer.exp_avg.copy_(st["exp_avg"]); trainer.exp_avg_sq.copy_(st["exp_avg_sq"]); trainer.nstep = st["nstep"]
+        losses, val_losses, best, start_epoch = st["losses"], st["val_losses"], st["best"], st["epoch"] + 1
+        print("Resumed from epoch", st["epoch"])
+
+    print("Start training...")
+    for epoch in range(start_epoch, num_epochs + 1):
+        model.train()
+        loader = tud.DataLoader(train_dataset, batch_size=batch_size, shuffle=True, collate_fn=collate_custom)
+        acc = torch.zeros((), device=dev)
+        for step, batch in enumerate(loader, 1):
+            loss = trainer.step(*_to_device(batch, dev))
+            acc += loss
+            if log_every and step % log_every == 0:
+                print("Step {}/{}. Loss: {:>4f}".format(step, len(loader), float(loss)))
+        losses.append(float(acc) / max(len(loader), 1))
+        np.save(os.path.join(model_path, "train_loss.npy"), np.array(losses))
+        print("Epoch:{}/{} Training loss:{:>4f}".format(epoch, num_epochs, losses[-1]))
+
+        curr = losses[-1]
+        if dev_dataset is not None:                                 # validation (model.py:246-268)
+            model.eval()
+            vl = torch.zeros((), device=dev)
+            vloader = tud.DataLoader(dev_dataset, batch_size=batch_size, shuffle=False, collate_fn=collate_custom)
+            with torch.no_grad():
+                for batch in vloader:
+                    x, t, fmask, tmask = _to_device(batch, dev)
+                    logits, in_len = model.logits(x, fmask)
+                    l, _, _, _ = pg_ctc_loss(logits, in_len, t.to(torch.int32).contiguous(),
+                                             tmask.sum(1).to(torch.int32).contiguous(), lam=0.0)
+                    vl += l
+            curr = float(vl) / max(len(vloader), 1)
+            val_losses.append(curr)
+            np.save(os.path.join(model_path, "val_losses.npy"), np.array(val_losses))
+            print("Epoch:{}/{} Validation loss:{:>4f}".format(epoch, num_epochs, curr))
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        if curr < best:                                             # model selection (model.py:270-274)
+            torch.save(sd, os.path.join(model_path, "model_best.pth"))
+            best = curr
+        torch.save(sd, os.path.join(model_path, "model_last.pth"))
+        torch.save({"model": sd, "exp_avg": trainer.exp_avg, "exp_avg_sq": trainer.exp_avg_sq, "nstep": trainer.nstep,
+                    "losses": losses, "val_losses": val_losses, "best": best, "epoch": epoch}, ckpt)
+    return losses, val_losses
+
+
+def predict(test_path, aud_path, alphabet_path, model_path, batch_size, maxlen=None, maxlent=None, device_id=0,
+            test_dataset=None, n_feats=120, beam_size=5):
+    """model.py:277-339: load model_best.pth, forward, beam=5 prefix search (device side, batched),
+    collapse_fn, CER/WER, predicted.txt.  Frames are cut by the FEATURE mask (the reference cuts the
+    time axis by the target mask, model.py:322 -- a listed defect).  Returns (CER, WER)."""
+    import os
+    import torch.utils.data as tud
+    from .CTCdecoder import CTCDecoder, collapse_fn
+    from .data import Data, collate_custom
+    from .metrics import evaluate, save_predictions
+
+    alphabet, char2ind = _read_alphabet(alphabet_path)
+    ind2char = {char2ind[k]: k for k in char2ind}
+    dev = torch.device("cuda", device_id)
+    model = Seq2Seq(alphabet_size=len(alphabet), n_feats=n_feats)
+    model.load_state_dict(torch.load(os.path.join(model_path, "model_best.pth"), map_location="cpu"))
+    model = model.to(dev).eval()
+    if test_dataset is None:
+        test_dataset = Data(test_path, aud_path, char2ind)
+    loader = tud.DataLoader(test_dataset, batch_size=batch_size, shuffle=False, collate_fn=collate_custom)
+    decoder = CTCDecoder(alphabet)
+    targets, predicted, tot_cer, tot_wer, n = [], [], 0.0, 0.0, 0
+    print("Total number of examples: ", len(test_dataset))
+    with torch.no_grad():
+        for step, batch in enumerate(loader, 1):
+            print("Decoding step {}/{}...".format(step, len(loader)))
+            x, t, fmask, tmask = _to_device(batch, dev)
+            logits, in_len = model.logits(x, fmask)
+            lp = Fh.LogSoftmaxFn.apply(logits)
+            tok, tl, _ = decoder.decode_batch(lp, in_len, beam_size=beam_size)
+            tok, tl, t, tmask = tok.cpu(), tl.cpu(), t.cpu(), tmask.cpu()
+            for i in range(tok.shape[0]):
+                seq = collapse_fn("".join(ind2char[int(k)] for k in tok[i, :tl[i]]))
+                target = "".join(ind2char[int(k)] for k in t[i][:int(tmask[i].sum())])
+                targets.append(target); predicted.append(seq)
+                cer, wer = evaluate(target, seq)
+                tot_cer += cer; tot_wer += wer; n += 1
+    save_predictions(targets, predicted, model_path)
+    cer, wer = tot_cer / max(n, 1), tot_wer / max(n, 1)
+    print("CER: {:>4f} WER: {:>4f}".format(cer, wer))
+    return cer, wer
