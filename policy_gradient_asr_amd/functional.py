@@ -200,6 +200,10 @@ class BLSTMLayerFn(torch.autograd.Function):
         if grad_overlap.enabled and all(t is not None and t.is_contiguous() for t in targets):
             side = grad_overlap.side_stream()
             side.wait_stream(torch.cuda.current_stream())
+            # (Confining these GEMMs to "the other" XCD slots was tried and measured WORSE: blockIdx % 8
+            # says which workgroups share an XCD, not which XCD, and the two streams' dispatch offsets
+            # differ -- the sweep went from 2.2 to 2.9 ms; a 1-D masked launch also ran the GEMMs
+            # 13-30 % slower than the 3-D grid.  All XCDs are used.)
             with torch.cuda.stream(side):
                 weight_grads(accumulate_into=targets)
             for t_ in (dg, x, out):
