@@ -190,7 +190,8 @@ int pgasr_lstm_layer_bwd(float* gates, const float* out, const float* cbuf, cons
 /* ------------------------------------------------------------------------------------------
  * A7  CTC prefix beam search (CTCdecoder.py:41-116), one workgroup per utterance.
  *   log_probs: natural-log probabilities, element (t,b,v) at log_probs[t*stride_t + b*stride_b + v],
- *              fp32 (is_f64 = 0) or fp64 (is_f64 != 0; the drop-in CTCDecoder.decode passes
+ *              fp32 (is_f64 = 0: fp64 score carries, fp32 exp/log on differences, ~1e-7 relative) or
+ *              fp64 (is_f64 != 0: exact fp64 math; the drop-in CTCDecoder.decode passes
  *              numpy's log of its probability matrix, like CTCdecoder.py:55);
  *   lengths (B) frames per utterance (NULL = T); beam <= 128, V <= 64, beam*V LDS-limited.
  *   out_tokens (B,T) best prefix, out_len (B), out_score (B) = -logsumexp(p_blank, p_nonblank)

@@ -56,6 +56,23 @@ __device__ __forceinline__ double lse3(double a, double b, double c) {
     return m + log((exp(a - m) + exp(b - m)) + exp(c - m));
 }
 
+// Fast variants (fp32 device log-probs, training-time rewards): fp64 carries, fp32 exp/log on the
+// differences to the maximum -- the software fp64 transcendentals dominate the exact path (28 ms
+// vs ~1/4 of that for T=1000, beam 16, 32 utterances).  Scores differ from the exact path by
+// ~1e-7 relative, so only exact score ties could rank differently.
+template <bool FAST> __device__ __forceinline__ double lse2x(double a, double b) {
+    if (!FAST) return lse2(a, b);
+    const double m = fmax(a, b);
+    if (m == -INFINITY) return -INFINITY;
+    return m + (double)__logf(__expf((float)(a - m)) + __expf((float)(b - m)));
+}
+template <bool FAST> __device__ __forceinline__ double lse3x(double a, double b, double c) {
+    if (!FAST) return lse3(a, b, c);
+    const double m = fmax(fmax(a, b), c);
+    if (m == -INFINITY) return -INFINITY;
+    return m + (double)__logf((__expf((float)(a - m)) + __expf((float)(b - m))) + __expf((float)(c - m)));
+}
+
 // order-preserving map double -> u64 (ascending)
 __device__ __forceinline__ unsigned long long ordered_key(double x) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(x);
@@ -68,7 +85,7 @@ __device__ __forceinline__ bool item_less(const SortItem& a, const SortItem& b) 
     return a.key < b.key || (a.key == b.key && a.time < b.time);
 }
 
-template <typename TIn>
+template <typename TIn, bool FAST>
 __global__ __launch_bounds__(BEAM_THREADS) void beam_search_kernel(
     const TIn* __restrict__ lp, long long stride_t, long long stride_b, const int32_t* __restrict__ lengths,
     int T, int V, int K, int blank, BeamWs ws, int32_t* __restrict__ out_tokens, int32_t* __restrict__ out_len,
@@ -130,7 +147,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_search_kernel(
                 bool alive = true;
                 if (s == blank) {
                     // prefix j unchanged.  blank update (:78-82)
-                    npb = lse3(-INFINITY, cpb[j] + frame[blank], cpnb[j] + frame[blank]);
+                    npb = lse3x<FAST>(-INFINITY, cpb[j] + frame[blank], cpnb[j] + frame[blank]);
                     time = (unsigned)(blank * nb + j);
                     const int lj = clast[j];
                     if (lj >= 0 && lj != blank) {
@@ -142,16 +159,16 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_search_kernel(
                             double e1 = cpb[i] + pl, e2 = cpnb[i] + pl;               // extension of parent i by lj (:90-96)
                             const bool rep = (clast[i] == lj);
                             if (i < j) {
-                                npnb = rep ? lse2(npnb, e1) : lse3(npnb, e1, e2);
-                                npnb = lse2(npnb, own);
+                                npnb = rep ? lse2x<FAST>(npnb, e1) : lse3x<FAST>(npnb, e1, e2);
+                                npnb = lse2x<FAST>(npnb, own);
                             } else {
-                                npnb = lse2(npnb, own);
-                                npnb = rep ? lse2(npnb, e1) : lse3(npnb, e1, e2);
+                                npnb = lse2x<FAST>(npnb, own);
+                                npnb = rep ? lse2x<FAST>(npnb, e1) : lse3x<FAST>(npnb, e1, e2);
                             }
                             const unsigned tt = (unsigned)(lj * nb + (i < j ? i : j));
                             time = tt < time ? tt : time;
                         } else {
-                            npnb = lse2(npnb, own);
+                            npnb = lse2x<FAST>(npnb, own);
                             const unsigned tt = (unsigned)(lj * nb + j);
                             time = tt < time ? tt : time;
                         }
@@ -160,12 +177,12 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_search_kernel(
                     alive = false;          // merged into an existing entry's stay candidate
                 } else {
                     const double ps = frame[s];
-                    npnb = (s != clast[j]) ? lse3(-INFINITY, cpb[j] + ps, cpnb[j] + ps) : lse2(-INFINITY, cpb[j] + ps);
+                    npnb = (s != clast[j]) ? lse3x<FAST>(-INFINITY, cpb[j] + ps, cpnb[j] + ps) : lse2x<FAST>(-INFINITY, cpb[j] + ps);
                     time = (unsigned)(s * nb + j);
                 }
                 if (alive) {
                     c_pb[c] = npb; c_pnb[c] = npnb;
-                    it.key = ~ordered_key(lse2(npb, npnb));
+                    it.key = ~ordered_key(lse2x<FAST>(npb, npnb));
                     it.time = time; it.cand = (unsigned)c;
                 }
             }
@@ -173,18 +190,27 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_search_kernel(
         }
         __syncthreads();
         // ---- bitonic sort of P items ----
-        for (int k2 = 2; k2 <= P; k2 <<= 1) {
-            for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-                for (int i = tid; i < P; i += BEAM_THREADS) {
-                    const int l = i ^ j2;
-                    if (l > i) {
-                        const SortItem x = items[i], y = items[l];
-                        const bool up = ((i & k2) == 0);
-                        if (item_less(y, x) == up) { items[i] = y; items[l] = x; }
+        // Element i is handled by thread i % 256, so all elements of a 64-aligned group belong to one
+        // wave: a pass with partner distance j2 < 64 exchanges only inside a wave (LDS accesses of one
+        // wave are ordered) and needs a workgroup barrier only next to a cross-wave pass.
+        {
+            bool prev_cross = false;   // the candidate loop above ended with __syncthreads()
+            for (int k2 = 2; k2 <= P; k2 <<= 1) {
+                for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                    const bool cross = j2 >= 64;
+                    if (cross || prev_cross) __syncthreads();
+                    for (int i = tid; i < P; i += BEAM_THREADS) {
+                        const int l = i ^ j2;
+                        if (l > i) {
+                            const SortItem x = items[i], y = items[l];
+                            const bool up = ((i & k2) == 0);
+                            if (item_less(y, x) == up) { items[i] = y; items[l] = x; }
+                        }
                     }
+                    prev_cross = cross;
                 }
-                __syncthreads();
             }
+            __syncthreads();
         }
         // ---- new beam ----
         const int nxt = cur ^ 1;
@@ -233,7 +259,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_search_kernel(
         int32_t* o = out_tokens + (size_t)b * T;
         int k = n - 1;
         for (int v = best; v > 0; v = (int)(nodes[v] >> 8)) o[k--] = (int32_t)(nodes[v] & 0xFFu);
-        out_score[b] = -lse2(pb[cur * K], pnb[cur * K]);
+        out_score[b] = -lse2x<FAST>(pb[cur * K], pnb[cur * K]);
     }
 }
 
@@ -273,13 +299,13 @@ extern "C" int pgasr_ctc_beam_search(const void* log_probs, int is_f64, long lon
     if (hipMemsetAsync(ws.table, 0, (size_t)B * ws.H * sizeof(unsigned long long), st) != hipSuccess) return PGASR_ERR_LAUNCH;
     const size_t lds = beam_lds_bytes(beam, V);
     if (lds > 160 * 1024) return PGASR_ERR_UNSUPPORTED;
-    if (is_f64) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&beam_search_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        PGASR_LAUNCH_KERNEL(beam_search_kernel<double>, dim3(B), dim3(BEAM_THREADS), lds, st, (const double*)log_probs,
+    if (is_f64) {   // exact path: fp64 transcendentals (drop-in CTCDecoder.decode)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&beam_search_kernel<double, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        PGASR_LAUNCH_KERNEL((beam_search_kernel<double, false>), dim3(B), dim3(BEAM_THREADS), lds, st, (const double*)log_probs,
                            stride_t, stride_b, lengths, T, V, beam, blank, ws, out_tokens, out_len, out_score);
-    } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&beam_search_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        PGASR_LAUNCH_KERNEL(beam_search_kernel<float>, dim3(B), dim3(BEAM_THREADS), lds, st, (const float*)log_probs,
+    } else {        // fp32 device log-probs: fast transcendentals
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&beam_search_kernel<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        PGASR_LAUNCH_KERNEL((beam_search_kernel<float, true>), dim3(B), dim3(BEAM_THREADS), lds, st, (const float*)log_probs,
                            stride_t, stride_b, lengths, T, V, beam, blank, ws, out_tokens, out_len, out_score);
     }
     PGASR_CHECK_LAUNCH();
