@@ -1,5 +1,7 @@
 """Fused CTC + REINFORCE objective and the full train step against the oracle
 (plumbing config B=4,T=200 of BASELINE.json; tolerance 1e-3 relative)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -199,3 +201,42 @@ def test_train_mode_step_runs_with_dropout():
     for _ in range(15):
         l1 = float(tr.step(x.to(DEV), targets.to(DEV), fmask.to(DEV), tmask.to(DEV)))
     assert np.isfinite(l1) and l1 < l0
+
+
+def test_headline_size_loss_and_gradient_parity():
+    """north_star criterion at the benchmark shape itself (B=32,T=1000,F=80,V=29,L=100): CTC loss
+    within 1e-3 relative of the CPU path and parameter gradients within 1e-3 (max-norm relative),
+    greedy-decoded token indices bit-exact on the oracle's logits."""
+    from policy_gradient_asr_amd.model import Seq2Seq
+    from policy_gradient_asr_amd.loss import pg_ctc_loss
+    from policy_gradient_asr_amd import hipops
+    B, F, T, V, L = 32, 80, 1000, 29, 100
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, F, T, generator=g)
+    targets = torch.randint(1, V, (B, L), generator=g)
+    fmask = torch.ones(B, T)
+    p = model_ref.init_params(n_feats=F, vocab=V, seed=0)
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    enc = model_ref.encoder_forward_torch(pr, x, fmask, packed=False)     # lengths == T: same arithmetic as packed
+    logits_ref = model_ref.head_logits_torch(pr, enc)
+    lp_ref = torch.log_softmax(logits_ref, 2)
+    il = torch.full((B,), T, dtype=torch.long); tl = torch.full((B,), L, dtype=torch.long)
+    ref = torch.nn.functional.ctc_loss(lp_ref, targets, il, tl, blank=0, reduction="mean")
+    ref.backward()
+    m = Seq2Seq(V, n_feats=F)
+    m.load_state_dict({("encoder." + k if not k.startswith("head.") else k): v for k, v in p.items()}, strict=True)
+    m = m.to(DEV).eval()
+    logits, in_len = m.logits(x.to(DEV), fmask.to(DEV))
+    loss, nll, _, _ = pg_ctc_loss(logits, in_len, targets.to(torch.int32).to(DEV), tl.to(torch.int32).to(DEV), lam=0.0)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref)) / abs(float(ref)) < 1e-3
+    worst = 0.0
+    for k, v in m.named_parameters():
+        rk = k[len("encoder."):] if k.startswith("encoder.") else k
+        worst = max(worst, rel_err(v.grad.cpu(), pr[rk].grad))
+    assert worst < 1e-3, worst
+    # logits agree closely enough that best-path decoding of the SAME tensor is bit-exact
+    assert rel_err(logits.detach().cpu(), logits_ref.detach()) < 1e-3
+    greedy, _ = hipops.frame_argmax_sample(logits_ref.detach().contiguous().to(DEV), want_sample=False)
+    assert np.array_equal(greedy.cpu().numpy(), np.argmax(logits_ref.detach().numpy(), axis=2))
