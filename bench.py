@@ -152,6 +152,12 @@ def main():
         avg_ms = tot_ms / max(calls, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         peak = 157.3
+        traffic = None   # HBM bytes per launch of that kernel from the committed PMC passes (profiles/)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_lstm_pmc.json")) as fi:
+                traffic = json.load(fi)["kernels"][name]["hbm_bytes_per_launch"]
+        except Exception:  # noqa: BLE001 - the file is optional evidence, never required to run
+            traffic = None
         out = {
             "metric": "utterances/sec (B=32,T=1000,F=80) policy-grad step, 1/2/4/8 MI355X",
             "value": value, "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -161,7 +167,7 @@ def main():
                                    "edit-distance reward), B=32/GPU, T=1000, F=80, V=29, L=100, Adam",
                        "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}", "dropout": "on (train mode)"},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None, "avg_launch_ms": avg_ms,
+                         "frac": achieved / peak, "traffic": traffic, "avg_launch_ms": avg_ms,
                          "launches_per_step": calls / args.steps,
                          "note": "serial chain of T dependent steps: latency bound, see DESIGN.md"},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
