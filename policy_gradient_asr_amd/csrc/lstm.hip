@@ -57,10 +57,12 @@ struct LstmArgs {
     const u32x4* wpack;      // packed bf16 hi/lo W_hh in MFMA A-operand order (see pack kernel)
     unsigned char* xbuf;     // exchange buffers, pre-filled with the "stale" pattern
     unsigned* hello;         // [clusters][16] start-up words (XCC id of each member), zeroed per call
+    unsigned* progress;      // [clusters] current step of member 0 (paces the prefetcher), zeroed per call
     int* err;                // set to 1 when a bounded wait gives up
     const int* lengths;      // [B]
     int T, B, NBG, NCL8;
     int force_mode;          // 0 auto, 1 force write-through (cross-XCD safe), for tests
+    int diag;                // diagnostic timing switches (results invalid): bit0 skip bulk stores, bit1 skip xproj prefetch
     long long* stamps;       // diagnostic build only (-DPGASR_LSTM_STAMPS)
 };
 
@@ -92,6 +94,15 @@ __device__ __forceinline__ void split_plain(float x, unsigned short& hi, unsigne
     lo = f2bf(x - bf2f(hi));
 }
 __device__ __forceinline__ unsigned or4(u32x4 v) { return (v.x | v.y) | (v.z | v.w); }
+// non-zero iff some word's (bit0, bit16) differs from the wanted pattern
+__device__ __forceinline__ unsigned bad4(u32x4 v, unsigned want) {
+    return (((v.x ^ want) | (v.y ^ want)) | ((v.z ^ want) | (v.w ^ want))) & 0x00010001u;
+}
+
+// Every polling attempt starts with this: the exchange buffers are written by OTHER workgroups, which the
+// compiler cannot see.  Without it the (side-effect free) buffer loads may legally be hoisted out of the
+// retry loop, or the loop deleted outright (observed on a microbenchmark with hipcc 7.2).
+#define POLL_FENCE() asm volatile("" ::: "memory")
 
 struct SpinGuard {
     unsigned spins = 0; long long t0 = 0;
@@ -121,6 +132,7 @@ __device__ __forceinline__ bool cluster_same_xcd(const LstmArgs& a, int cl, int 
         SpinGuard sg;
         unsigned v = 0x100u | xcc;
         while (true) {
+            POLL_FENCE();
             if (tid < 16) v = __hip_atomic_load(hw + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!__any(v == 0u)) break;
             if (!sg.keep_waiting()) { *s_abort = 1; *a.err = 1; break; }
@@ -132,8 +144,78 @@ __device__ __forceinline__ bool cluster_same_xcd(const LstmArgs& a, int cl, int 
     return *s_flag != 0;
 }
 
+
+// ---- the cluster's prefetcher workgroup (member index G_CLUSTER) ---------------------------
+// The compute waves must never wait on DRAM: vmcnt retires in order, so one HBM-latency load in
+// front of the polling loads delays the whole step (measured 0.4 us of a 1.6 us step).  The
+// prefetcher shares the cluster's XCD (same blockIdx % 8), follows member 0's progress word and
+// touches the lines the cluster will need PREFETCH_AHEAD steps from now (one 4-byte load per
+// 128-byte line), so that the compute waves' own loads hit in the XCD's L2.  It carries no data
+// and no correctness: if it lands on another XCD or falls behind, the sweep is merely slower.
+constexpr int PREFETCH_AHEAD = 6;
+
+__device__ __forceinline__ void prefetcher_loop(const LstmArgs& a, int cl, int dir, int bg, bool backward) {
+    const int tid = threadIdx.x;
+    const int T = a.T, B = a.B;
+    if (a.diag & 8) return;
+    // only useful on the cluster's own XCD: compare with member 0's start-up word, else leave
+    {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xFu;
+        SpinGuard sg0;
+        unsigned v;
+        while (true) {
+            POLL_FENCE();
+            v = __hip_atomic_load(a.hello + (size_t)cl * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != 0u) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (!sg0.keep_waiting()) return;
+        }
+        if ((v & 0xFu) != xcc) return;
+    }
+    // Fire-and-forget: LDS-DMA loads have no register result, so nothing ever waits for them (the
+    // hardware just caps the number in flight); their LDS landing zone is scratch.  One wave-instruction
+    // moves 1 KiB (64 lanes x 16 B) = a quarter of one utterance's 4-KiB gate slice.
+    __shared__ __attribute__((aligned(16))) unsigned char scratch[4 * 1024];
+    const int lane = tid & 63, w = tid >> 6;
+    SpinGuard sg;
+    for (int step = 0; step < T; ++step) {
+        while (true) {   // stay at most PREFETCH_AHEAD steps in front of the cluster; leave when it is done
+            POLL_FENCE();
+            const unsigned cur = __hip_atomic_load(a.progress + cl * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur + 1 >= (unsigned)T) return;
+            const unsigned ahead = (a.diag >> 5) ? (unsigned)(a.diag >> 5) : (unsigned)PREFETCH_AHEAD;   // diag bits 5-7 override
+            if ((unsigned)step <= cur + ahead) break;
+            __builtin_amdgcn_s_sleep(4);
+            if (!sg.keep_waiting()) return;
+        }
+        sg.spins = 0;
+        const int t = backward ? (dir ? step : T - 1 - step) : (dir ? T - 1 - step : step);
+        if (a.diag & 16) continue;
+        for (int n = 0; n < 16; ++n) {
+            const int b = bg * 16 + n;
+            if (b >= B) break;
+            const float* row = a.gates + ((((size_t)t * B + b) * 2 + dir) * HID) * 4;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(row + w * 256 + lane * 4),
+                                             (void __attribute__((address_space(3)))*)(scratch + w * 1024), 16, 0, 0);
+        }
+        if (backward) {
+            // c_t (also the next step's c_prev) and dout: 1 KiB per utterance each; wave w takes utterances w, w+4, ..
+            for (int k = 0; k < 4; ++k) {
+                const int b = bg * 16 + w + 4 * k;
+                if (b >= B) break;
+                const float* c = a.cbuf + (((size_t)t * B + b) * 2 + dir) * HID;
+                const float* d = a.dout + ((size_t)t * B + b) * (2 * HID) + dir * HID;
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(c + lane * 4),
+                                                 (void __attribute__((address_space(3)))*)(scratch + w * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(d + lane * 4),
+                                                 (void __attribute__((address_space(3)))*)(scratch + w * 1024), 16, 0, 0);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
-// forward sweep.  1-D grid of 16*NCL8 workgroups: cluster cl = b % NCL8 (members share b % 8,
+// forward sweep.  1-D grid of 17*NCL8 workgroups (16 compute members + 1 prefetcher per cluster): cluster cl = b % NCL8 (members share b % 8,
 // i.e. an XCD under the observed round-robin placement), member g = b / NCL8 owns hidden units
 // 16g..16g+15.  Wave w multiplies the k-quarter [64w, 64w+64) of h_{t-1} into all 64 gate rows
 // of the workgroup (4 MFMA tiles x 2 k-steps x 3 split terms); the four partial tiles are
@@ -145,6 +227,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
     const int cl = blockIdx.x % a.NCL8, g = blockIdx.x / a.NCL8;
     if (cl >= 2 * a.NBG) return;
     const int dir = cl & 1, bg = cl >> 1;
+    if (g == G_CLUSTER) { prefetcher_loop(a, cl, dir, bg, false); return; }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = lane >> 4, n = lane & 15;      // MFMA coordinates
     const int pu = tid & 15, pn = tid >> 4;      // cell coordinates (unit fastest: coalesced stores)
@@ -152,8 +235,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
     const int T = a.T, B = a.B;
 
     constexpr int PROW = 16 * 4 + 4;             // padded row of 16 units x 4 gates (conflict-free both ways)
-    __shared__ __attribute__((aligned(16))) float part[4 * 16 * PROW];          // [w][n][u][gate]
-    __shared__ __attribute__((aligned(16))) unsigned short hs[2 * 16 * 2 * 8];  // [c2][n][hl][8 units]
+    __shared__ __attribute__((aligned(16))) float part[2][4 * 16 * PROW];       // [step parity][w][n][u][gate]
     __shared__ volatile int s_abort;
     __shared__ volatile int s_same;
     if (tid == 0) { s_abort = 0; s_same = 0; }
@@ -186,7 +268,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
     // issued behind the next step's operand loads instead of in front of them
     float4 def_g = make_float4(0, 0, 0, 0); float def_c = 0.f, def_h = 0.f; int def_t = -1;
     auto flush_deferred = [&]() {
-        if (def_t >= 0 && bidx < B) {
+        if (def_t >= 0 && bidx < B && !(a.diag & 1)) {
             *gate_ptr(def_t) = def_g;
             a.cbuf[(((size_t)def_t * B + bidx) * 2 + dir) * HID + unit] = def_c;
             a.out[((size_t)def_t * B + bidx) * (2 * HID) + dir * HID + unit] = def_h;
@@ -196,16 +278,26 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
 
     for (int step = 0; step < T; ++step) {
         const int t = dir ? T - 1 - step : step;
+        if (g == 0 && tid == 0) {   // paces the prefetcher; a plain store (shared L2) unless the cluster spans XCDs
+            if (same_xcd) *reinterpret_cast<volatile unsigned*>(a.progress + cl * 32) = (unsigned)step;
+            else __hip_atomic_store(a.progress + cl * 32, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // next step's xproj: an L2 hit thanks to the cluster's prefetcher workgroup (below).  vmcnt retires
+        // in order, so a DRAM-latency load here would stall every poll behind it (measured 0.4 us/step).
         float4 xn = make_float4(0, 0, 0, 0);
-        if (step + 1 < T && bidx < B) xn = *gate_ptr(dir ? t - 1 : t + 1);
+        const bool early = (a.diag & 64) == 0;   // ahead of the polls (measured faster); diag 64: after them
+        if (early && step + 1 < T && bidx < B && !(a.diag & 2)) xn = *gate_ptr((a.diag & 4) ? 0 : (dir ? t - 1 : t + 1));
         float4 pre = xg;
         STAMP(0);
+        bf16x8 Hhi[2], Hlo[2];
         if (step > 0) {
             const unsigned pbase = (unsigned)((step - 1) & 1) * SLOT;
-            const unsigned stale_bit = (((step - 1) >> 1) & 1) ? 0x00010000u : 0x00000001u;
-            bf16x8 Hhi[2], Hlo[2];
+            // fresh word of epoch e: (bit0, bit16) = (e, 1-e); the two halves of a word are written by
+            // different lanes (2-byte stores), so BOTH bits are checked
+            const unsigned want = (((step - 1) >> 1) & 1) ? 0x00000001u : 0x00010000u;
             u32x4 vh[2], vl[2];
             auto issue_loads = [&]() {
+                POLL_FENCE();
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const unsigned off = pbase + (unsigned)((((4 * (2 * w + i) + q) * 16 + n) * 2) * 16);
@@ -217,8 +309,8 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
             flush_deferred();         // previous step's bulk stores ride behind them
             SpinGuard sg;
             while (true) {
-                const unsigned orr = (or4(vh[0]) | or4(vl[0])) | (or4(vh[1]) | or4(vl[1]));
-                if (!__any((orr & stale_bit) != 0)) break;
+                const unsigned bad = (bad4(vh[0], want) | bad4(vl[0], want)) | (bad4(vh[1], want) | bad4(vl[1], want));
+                if (!__any(bad != 0)) break;
                 if (s_abort || !sg.keep_waiting()) { s_abort = 1; *a.err = 1; break; }
                 issue_loads();
             }
@@ -228,6 +320,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
                 Hlo[i] = __builtin_bit_cast(bf16x8, vl[i]);
             }
             STAMP(1);
+        }
+        if (!early && step + 1 < T && bidx < B && !(a.diag & 2)) xn = *gate_ptr((a.diag & 4) ? 0 : (dir ? t - 1 : t + 1));
+        if (step > 0) {
             f32x4 acc[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -243,12 +338,12 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
             // tile m, lane (q,n): gates of local unit 4m+q for utterance n
 #pragma unroll
             for (int m = 0; m < 4; ++m)
-                *reinterpret_cast<float4*>(&part[(w * 16 + n) * PROW + (4 * m + q) * 4]) =
+                *reinterpret_cast<float4*>(&part[step & 1][(w * 16 + n) * PROW + (4 * m + q) * 4]) =
                     make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
             STAMP(2);
             __syncthreads();
             STAMP(3);
-            const float* pp = &part[pn * PROW + pu * 4];
+            const float* pp = &part[step & 1][pn * PROW + pu * 4];
             const float4 p0 = *reinterpret_cast<const float4*>(pp);
             const float4 p1 = *reinterpret_cast<const float4*>(pp + 16 * PROW);
             const float4 p2 = *reinterpret_cast<const float4*>(pp + 32 * PROW);
@@ -266,24 +361,26 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
         const float cn = gf * c + gi * gg;
         const float hn = go * tanhf_fast(cn);
         if (active) { c = cn; h = hn; }
-        {
+        if (s_abort) break;
+        if (step + 1 < T) {
+            // publish h_t: each cell thread writes its own bf16 hi and lo (2-byte stores, no LDS re-layout,
+            // no second barrier); layout [kc = unit/8][n][hl][unit%8] of this member's 1-KiB block
             const unsigned e = (unsigned)(step >> 1) & 1u;
             const unsigned tb = (pu & 1) ? (1u - e) : e;
             unsigned short hi, lo;
             split_tagged(h, tb, hi, lo);
-            hs[(((pu >> 3) * 16 + pn) * 2 + 0) * 8 + (pu & 7)] = hi;
-            hs[(((pu >> 3) * 16 + pn) * 2 + 1) * 8 + (pu & 7)] = lo;
+            const unsigned off = (unsigned)(step & 1) * SLOT + (unsigned)g * 1024u +
+                                 (unsigned)((((pu >> 3) * 16 + pn) * 2) * 16 + (pu & 7) * 2);
+            if (same_xcd) {
+                __builtin_amdgcn_raw_buffer_store_b16(hi, rsrc, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(lo, rsrc, off + 16, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b16(hi, rsrc, off, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b16(lo, rsrc, off + 16, 0, 16);
+            }
         }
         STAMP(4);
-        __syncthreads();
         STAMP(5);
-        if (s_abort) break;
-        if (w == 0 && step + 1 < T) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(&hs[lane * 8]);
-            const unsigned off = (unsigned)(step & 1) * SLOT + (unsigned)g * 1024u + (unsigned)lane * 16u;
-            if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 0);    // stays in the shared L2
-            else          __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 16);   // write-through (sc1)
-        }
         // results for the backward pass / next layer: stored at the top of the next step
         def_g = active ? make_float4(gi, gf, gg, go) : make_float4(0, 0, 0, 0);
         def_c = c; def_h = active ? hn : 0.f; def_t = t;
@@ -308,6 +405,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     const int cl = blockIdx.x % a.NCL8, g = blockIdx.x / a.NCL8;
     if (cl >= 2 * a.NBG) return;
     const int dir = cl & 1, bg = cl >> 1;
+    if (g == G_CLUSTER) { prefetcher_loop(a, cl, dir, bg, true); return; }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = lane >> 4, n = lane & 15;      // MFMA coordinates
     const int pu = tid & 15, pn = tid >> 4;      // cell coordinates (unit fastest: coalesced partial reads)
@@ -356,6 +454,11 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
 
     for (int step = 0; step < T; ++step) {
         const int t = dir ? step : T - 1 - step;
+        if (g == 0 && tid == 0) {   // paces the prefetcher; a plain store (shared L2) unless the cluster spans XCDs
+            if (same_xcd) *reinterpret_cast<volatile unsigned*>(a.progress + cl * 32) = (unsigned)step;
+            else __hip_atomic_store(a.progress + cl * 32, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // next step's saved activations: L2 hits thanks to the prefetcher workgroup (see forward sweep)
         Saved sn; sn.gt = make_float4(0, 0, 0, 0); sn.ct = sn.cp = sn.dy = 0.f;
         if (step + 1 < T) sn = load_saved(dir ? t + 1 : t - 1);
         float dh_rec = carry;
@@ -366,6 +469,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
             float v[16];
             SpinGuard sg;
             while (true) {
+                POLL_FENCE();
                 unsigned orr = 0;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
@@ -541,7 +645,7 @@ __global__ __launch_bounds__(256) void lstm_unpack_kernel(UnpackArgs u) {
     }
 }
 
-struct WsLayout { size_t err, hello, xbuf, xbytes, stamps, total; int NBG, NCL8; };
+struct WsLayout { size_t err, hello, progress, xbuf, xbytes, stamps, total; int NBG, NCL8; };
 WsLayout lstm_ws_layout(int B, bool backward) {
     WsLayout l;
     l.NBG = (B + 15) / 16;
@@ -550,7 +654,8 @@ WsLayout lstm_ws_layout(int B, bool backward) {
     const size_t slot = backward ? (size_t)16 * 16 * 256 * 4 : (size_t)32 * 16 * 2 * 16;
     l.err = 0;                                   // 256 bytes
     l.hello = 256;                               // [clusters][16] words; err+hello zeroed every call
-    l.xbuf = l.hello + pgasr_align_up((size_t)ncl * 16 * sizeof(unsigned), 256);
+    l.progress = l.hello + pgasr_align_up((size_t)ncl * 16 * sizeof(unsigned), 256);   // one 128-B line per cluster
+    l.xbuf = l.progress + pgasr_align_up((size_t)ncl * 128, 256);
     l.xbytes = (size_t)ncl * 2 * slot;           // [cluster][parity][slot], filled with 0x00000001 every call
     l.stamps = l.xbuf + l.xbytes;
     l.total = l.stamps;
@@ -624,13 +729,15 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
     LstmArgs a;
     a.gates = gates; a.out = out; a.cbuf = cbuf; a.dout = dout; a.wpack = (const u32x4*)wpack;
     a.xbuf = (unsigned char*)(ws + l.xbuf); a.hello = (unsigned*)(ws + l.hello); a.err = (int*)(ws + l.err);
+    a.progress = (unsigned*)(ws + l.progress);
     a.lengths = lengths; a.T = T; a.B = B; a.NBG = l.NBG; a.NCL8 = l.NCL8;
     a.force_mode = (flags & 1) ? 1 : 0;
+    a.diag = (flags >> 8) & 0xFF;
     a.stamps = (long long*)(ws + l.stamps);
 #ifdef PGASR_LSTM_STAMPS
     if (T > STAMP_MAX_T) return PGASR_ERR_UNSUPPORTED;
 #endif
-    dim3 grid(G_CLUSTER * l.NCL8);
+    dim3 grid((G_CLUSTER + 1) * l.NCL8);   // + one prefetcher workgroup per cluster
     if (backward) PGASR_LAUNCH_KERNEL(lstm_bwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
     else PGASR_LAUNCH_KERNEL(lstm_fwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
     PGASR_CHECK_LAUNCH();
