@@ -24,7 +24,7 @@ namespace {
 
 constexpr int HID = 256;           // hidden size per direction (model.py:40)
 constexpr int G_CLUSTER = 16;      // workgroups per (direction, batch group): 16 units each
-constexpr int LSTM_THREADS = 256;
+constexpr int LSTM_THREADS = 384;     // 4 compute waves + loader wave + storer wave
 constexpr int STAMP_MAX_T = 4096;
 constexpr long long SPIN_TIMEOUT_TICKS = 300000000LL;  // 3 s of the 100 MHz realtime counter
 
@@ -104,6 +104,12 @@ __device__ __forceinline__ unsigned bad4(u32x4 v, unsigned want) {
 // retry loop, or the loop deleted outright (observed on a microbenchmark with hipcc 7.2).
 #define POLL_FENCE() asm volatile("" ::: "memory")
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also drains vmcnt (it is a
+// workgroup-scope fence), i.e. every wave would wait at every step for all of its outstanding global
+// loads and stores -- for the I/O wave that is a DRAM round trip per step.  Global data here is ordered
+// by the exchange protocol itself, never by this barrier.
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 struct SpinGuard {
     unsigned spins = 0; long long t0 = 0;
     // returns false when the wait has lasted longer than SPIN_TIMEOUT_TICKS
@@ -177,6 +183,7 @@ __device__ __forceinline__ void prefetcher_loop(const LstmArgs& a, int cl, int d
     // moves 1 KiB (64 lanes x 16 B) = a quarter of one utterance's 4-KiB gate slice.
     __shared__ __attribute__((aligned(16))) unsigned char scratch[4 * 1024];
     const int lane = tid & 63, w = tid >> 6;
+    if (w >= 4) return;      // four waves are enough (no barriers in here)
     SpinGuard sg;
     for (int step = 0; step < T; ++step) {
         while (true) {   // stay at most PREFETCH_AHEAD steps in front of the cluster; leave when it is done
@@ -215,13 +222,35 @@ __device__ __forceinline__ void prefetcher_loop(const LstmArgs& a, int cl, int d
 }
 
 // ------------------------------------------------------------------------------------------
-// forward sweep.  1-D grid of 17*NCL8 workgroups (16 compute members + 1 prefetcher per cluster): cluster cl = b % NCL8 (members share b % 8,
-// i.e. an XCD under the observed round-robin placement), member g = b / NCL8 owns hidden units
-// 16g..16g+15.  Wave w multiplies the k-quarter [64w, 64w+64) of h_{t-1} into all 64 gate rows
-// of the workgroup (4 MFMA tiles x 2 k-steps x 3 split terms); the four partial tiles are
-// summed through LDS and each thread finishes ONE (unit, utterance) cell.
-// exchange slot per cluster: [parity 2][kc 32][n 16][hl 2][8 bf16]; producer g owns
-// kc = 2g, 2g+1 = one contiguous 1-KiB block written by ONE wave-instruction.
+// Workgroup anatomy of both sweeps: 6 waves.  Waves 0-3 compute (MFMA + cell math) and touch
+// global memory ONLY for the exchange.  Wave 4 is the LOADER: it streams the rows the cells need
+// (xproj / saved activations) a few steps ahead straight into an LDS ring with LDS-DMA
+// (global_load_lds: no register result) behind a hand-counted s_waitcnt vmcnt(N).  Wave 5 is the
+// STORER: it copies the cells' results (staged in LDS) to HBM and never waits on memory.
+// Reason (measured, tools_lstm_diag.py): vmcnt retires in order and hipcc emits only vmcnt(0) in
+// this kernel, so any DRAM-latency load or scattered store issued by a compute wave sits in
+// front of its polling loads -- the sweep ran 1.63 ms with that traffic in the compute waves and
+// 1.05 ms without it, while a cached load in the same place cost nothing.
+// ------------------------------------------------------------------------------------------
+constexpr int IO_WAVE = 4;        // first non-compute wave
+constexpr int LOADER_WAVE = 4, STORER_WAVE = 5;
+constexpr int FWD_LEAD = 3, FWD_RING = 5;   // loader runs 3 steps ahead; ring slot reuse distance 5 > lead + 1
+constexpr int BWD_LEAD = 4, BWD_RING = 6;
+
+// one LDS-DMA wave-instruction: 64 lanes x 16 B, per-lane global source, LDS destination = base + lane*16
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                     (void __attribute__((address_space(3)))*)lds_base, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// forward sweep.  1-D grid of 17*NCL8 workgroups (16 compute members + 1 prefetcher per cluster):
+// cluster cl = b % NCL8 (members share b % 8, i.e. an XCD under the observed round-robin
+// placement), member g = b / NCL8 owns hidden units 16g..16g+15.  Wave w < 4 multiplies the
+// k-quarter [64w, 64w+64) of h_{t-1} into all 64 gate rows of the workgroup (4 MFMA tiles x 2
+// k-steps x 3 split terms); the four partial tiles are summed through LDS and each compute thread
+// finishes ONE (unit, utterance) cell.
+// exchange slot per cluster: [parity 2][kc 32][n 16][hl 2][8 bf16]; member g owns kc = 2g, 2g+1.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
     const int cl = blockIdx.x % a.NCL8, g = blockIdx.x / a.NCL8;
@@ -230,12 +259,15 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
     if (g == G_CLUSTER) { prefetcher_loop(a, cl, dir, bg, false); return; }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = lane >> 4, n = lane & 15;      // MFMA coordinates
-    const int pu = tid & 15, pn = tid >> 4;      // cell coordinates (unit fastest: coalesced stores)
-    const int unit = 16 * g + pu;
+    const int pu = tid & 15, pn = (tid >> 4) & 15;   // cell coordinates of a compute thread (unit fastest)
     const int T = a.T, B = a.B;
 
     constexpr int PROW = 16 * 4 + 4;             // padded row of 16 units x 4 gates (conflict-free both ways)
     __shared__ __attribute__((aligned(16))) float part[2][4 * 16 * PROW];       // [step parity][w][n][u][gate]
+    __shared__ __attribute__((aligned(16))) float4 xin[FWD_RING][256];          // xproj ring (filled by LDS-DMA), by cell id
+    __shared__ __attribute__((aligned(16))) float4 rg[2][256];                  // results: gate activations
+    __shared__ __attribute__((aligned(16))) float rc[2][256];                   //          c_t
+    __shared__ __attribute__((aligned(16))) float rh[2][256];                   //          h_t (0 past the length)
     __shared__ volatile int s_abort;
     __shared__ volatile int s_same;
     if (tid == 0) { s_abort = 0; s_same = 0; }
@@ -243,13 +275,15 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
 
     // weight slices -> registers: tile m (units 4(4g+m)..+3, row = 4*uu+gate), k-steps 2w, 2w+1
     bf16x8 Whi[4][2], Wlo[4][2];
+    if (w < IO_WAVE) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const u32x4* wp = a.wpack + ((size_t)(dir * 64 + 4 * g + m) * 8) * 2 * 64;
+        for (int m = 0; m < 4; ++m) {
+            const u32x4* wp = a.wpack + ((size_t)(dir * 64 + 4 * g + m) * 8) * 2 * 64;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            Whi[m][i] = __builtin_bit_cast(bf16x8, wp[((2 * w + i) * 2 + 0) * 64 + lane]);
-            Wlo[m][i] = __builtin_bit_cast(bf16x8, wp[((2 * w + i) * 2 + 1) * 64 + lane]);
+            for (int i = 0; i < 2; ++i) {
+                Whi[m][i] = __builtin_bit_cast(bf16x8, wp[((2 * w + i) * 2 + 0) * 64 + lane]);
+                Wlo[m][i] = __builtin_bit_cast(bf16x8, wp[((2 * w + i) * 2 + 1) * 64 + lane]);
+            }
         }
     }
     constexpr unsigned SLOT = 32 * 16 * 2 * 16;       // bytes per parity slot (16 KiB)
@@ -260,144 +294,168 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
     const int bidx = bg * 16 + pn;
     const int len = (bidx < B) ? a.lengths[bidx] : 0;
     float c = 0.f, h = 0.f;
-    auto gate_ptr = [&](int t) {
-        return reinterpret_cast<float4*>(a.gates + ((((size_t)t * B + bidx) * 2 + dir) * HID + unit) * 4);
-    };
-    float4 xg = (bidx < B) ? *gate_ptr(dir ? T - 1 : 0) : make_float4(0, 0, 0, 0);
-    // results of the previous step, stored one step late so that their (scattered) stores are
-    // issued behind the next step's operand loads instead of in front of them
-    float4 def_g = make_float4(0, 0, 0, 0); float def_c = 0.f, def_h = 0.f; int def_t = -1;
-    auto flush_deferred = [&]() {
-        if (def_t >= 0 && bidx < B && !(a.diag & 1)) {
-            *gate_ptr(def_t) = def_g;
-            a.cbuf[(((size_t)def_t * B + bidx) * 2 + dir) * HID + unit] = def_c;
-            a.out[((size_t)def_t * B + bidx) * (2 * HID) + dir * HID + unit] = def_h;
-        }
-        def_t = -1;
-    };
 
-    for (int step = 0; step < T; ++step) {
-        const int t = dir ? T - 1 - step : step;
-        if (g == 0 && tid == 0) {   // paces the prefetcher; a plain store (shared L2) unless the cluster spans XCDs
-            if (same_xcd) *reinterpret_cast<volatile unsigned*>(a.progress + cl * 32) = (unsigned)step;
-            else __hip_atomic_store(a.progress + cl * 32, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- loader / storer: lane L serves cells 64k+L (k = 0..3) for 16-byte rows, cells 4L..4L+3 for 4-byte rows
+    auto step_t = [&](int s) { return dir ? T - 1 - s : s; };
+    auto gate_addr = [&](int t, int cell) {
+        const int b = bg * 16 + (cell >> 4);
+        return reinterpret_cast<float4*>(a.gates + ((((size_t)t * B + b) * 2 + dir) * HID + 16 * g + (cell & 15)) * 4);
+    };
+    // 4 LDS-DMA instructions per step, ALWAYS issued (step and utterance clamped into range) so that the
+    // counted wait below is exact: vmcnt(4*FWD_LEAD) leaves only the loads of the next FWD_LEAD steps in flight
+    auto loader_issue = [&](int s) {
+        if (a.diag & 2) return;
+        const int t = step_t(s < T ? s : T - 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cell = 64 * k + lane;
+            int b = bg * 16 + (cell >> 4); b = b < B ? b : B - 1;
+            dma16(a.gates + ((((size_t)t * B + b) * 2 + dir) * HID + 16 * g + (cell & 15)) * 4, &xin[s % FWD_RING][64 * k]);
         }
-        // next step's xproj: an L2 hit thanks to the cluster's prefetcher workgroup (below).  vmcnt retires
-        // in order, so a DRAM-latency load here would stall every poll behind it (measured 0.4 us/step).
-        float4 xn = make_float4(0, 0, 0, 0);
-        const bool early = (a.diag & 64) == 0;   // ahead of the polls (measured faster); diag 64: after them
-        if (early && step + 1 < T && bidx < B && !(a.diag & 2)) xn = *gate_ptr((a.diag & 4) ? 0 : (dir ? t - 1 : t + 1));
-        float4 pre = xg;
-        STAMP(0);
-        bf16x8 Hhi[2], Hlo[2];
-        if (step > 0) {
-            const unsigned pbase = (unsigned)((step - 1) & 1) * SLOT;
-            // fresh word of epoch e: (bit0, bit16) = (e, 1-e); the two halves of a word are written by
-            // different lanes (2-byte stores), so BOTH bits are checked
-            const unsigned want = (((step - 1) >> 1) & 1) ? 0x00000001u : 0x00010000u;
-            u32x4 vh[2], vl[2];
-            auto issue_loads = [&]() {
-                POLL_FENCE();
+    };
+    auto io_store_results = [&](int s) {      // results of step s: 4 + 1 + 1 sixteen-byte stores per lane
+        if (a.diag & 1) return;
+        const int t = step_t(s), par = s & 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cell = 64 * k + lane;
+            if (bg * 16 + (cell >> 4) < B) *gate_addr(t, cell) = rg[par][cell];
+        }
+        const int cell0 = 4 * lane, b = bg * 16 + (cell0 >> 4), u0 = 16 * g + (cell0 & 15);
+        if (b < B) {
+            *reinterpret_cast<float4*>(a.cbuf + (((size_t)t * B + b) * 2 + dir) * HID + u0) = *reinterpret_cast<const float4*>(&rc[par][cell0]);
+            *reinterpret_cast<float4*>(a.out + ((size_t)t * B + b) * (2 * HID) + dir * HID + u0) = *reinterpret_cast<const float4*>(&rh[par][cell0]);
+        }
+    };
+    if (w == LOADER_WAVE) {
+        for (int s = 0; s < FWD_LEAD; ++s) loader_issue(s);
+    }
+
+    {
+        for (int step = 0; step < T; ++step) {
+            const int t = step_t(step);
+            if (w == LOADER_WAVE) {
+                loader_issue(step + FWD_LEAD);
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // = 4*FWD_LEAD: this step's rows have landed
+            }
+            if (g == 0 && tid == 0) {   // paces the prefetcher; a plain store (shared L2) unless the cluster spans XCDs
+                if (same_xcd) *reinterpret_cast<volatile unsigned*>(a.progress + cl * 32) = (unsigned)step;
+                else __hip_atomic_store(a.progress + cl * 32, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            STAMP(0);
+            if (w < IO_WAVE && step > 0) {
+                const unsigned pbase = (unsigned)((step - 1) & 1) * SLOT;
+                // fresh word of epoch e: (bit0, bit16) = (e, 1-e); the two halves of a word are written by
+                // different lanes (2-byte stores), so BOTH bits are checked
+                const unsigned want = (((step - 1) >> 1) & 1) ? 0x00000001u : 0x00010000u;
+                u32x4 vh[2], vl[2];
+                auto issue_loads = [&]() {
+                    POLL_FENCE();
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const unsigned off = pbase + (unsigned)((((4 * (2 * w + i) + q) * 16 + n) * 2) * 16);
+                        vh[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
+                        vl[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 16);
+                    }
+                };
+                issue_loads();            // the operand loads ARE the poll
+                SpinGuard sg;
+                while (true) {
+                    const unsigned bad = (bad4(vh[0], want) | bad4(vl[0], want)) | (bad4(vh[1], want) | bad4(vl[1], want));
+                    if (!__any(bad != 0)) break;
+                    if (s_abort || !sg.keep_waiting()) { s_abort = 1; *a.err = 1; break; }
+                    issue_loads();
+                }
+                STAMP(1);
+                bf16x8 Hhi[2], Hlo[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const unsigned off = pbase + (unsigned)((((4 * (2 * w + i) + q) * 16 + n) * 2) * 16);
-                    vh[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
-                    vl[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 16);
+                    Hhi[i] = __builtin_bit_cast(bf16x8, vh[i]);
+                    Hlo[i] = __builtin_bit_cast(bf16x8, vl[i]);
                 }
-            };
-            issue_loads();            // the operand loads ARE the poll
-            flush_deferred();         // previous step's bulk stores ride behind them
-            SpinGuard sg;
-            while (true) {
-                const unsigned bad = (bad4(vh[0], want) | bad4(vl[0], want)) | (bad4(vh[1], want) | bad4(vl[1], want));
-                if (!__any(bad != 0)) break;
-                if (s_abort || !sg.keep_waiting()) { s_abort = 1; *a.err = 1; break; }
-                issue_loads();
+                f32x4 acc[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[m][i], Hhi[i], acc[m], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[m][i], Hlo[i], acc[m], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wlo[m][i], Hhi[i], acc[m], 0, 0, 0);
+                }
+                // tile m, lane (q,n): gates of local unit 4m+q for utterance n
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    *reinterpret_cast<float4*>(&part[step & 1][(w * 16 + n) * PROW + (4 * m + q) * 4]) =
+                        make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+                STAMP(2);
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                Hhi[i] = __builtin_bit_cast(bf16x8, vh[i]);
-                Hlo[i] = __builtin_bit_cast(bf16x8, vl[i]);
-            }
-            STAMP(1);
-        }
-        if (!early && step + 1 < T && bidx < B && !(a.diag & 2)) xn = *gate_ptr((a.diag & 4) ? 0 : (dir ? t - 1 : t + 1));
-        if (step > 0) {
-            f32x4 acc[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[m][i], Hhi[i], acc[m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[m][i], Hlo[i], acc[m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wlo[m][i], Hhi[i], acc[m], 0, 0, 0);
-            }
-            // tile m, lane (q,n): gates of local unit 4m+q for utterance n
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-                *reinterpret_cast<float4*>(&part[step & 1][(w * 16 + n) * PROW + (4 * m + q) * 4]) =
-                    make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
-            STAMP(2);
-            __syncthreads();
+            LDS_BARRIER();        // partial tiles + this step's xproj visible; previous step's results visible to the I/O wave
             STAMP(3);
-            const float* pp = &part[step & 1][pn * PROW + pu * 4];
-            const float4 p0 = *reinterpret_cast<const float4*>(pp);
-            const float4 p1 = *reinterpret_cast<const float4*>(pp + 16 * PROW);
-            const float4 p2 = *reinterpret_cast<const float4*>(pp + 32 * PROW);
-            const float4 p3 = *reinterpret_cast<const float4*>(pp + 48 * PROW);
-            pre.x += (p0.x + p1.x) + (p2.x + p3.x);
-            pre.y += (p0.y + p1.y) + (p2.y + p3.y);
-            pre.z += (p0.z + p1.z) + (p2.z + p3.z);
-            pre.w += (p0.w + p1.w) + (p2.w + p3.w);
-        }
-        const float gi = sigmoidf_fast(pre.x);
-        const float gf = sigmoidf_fast(pre.y);
-        const float gg = tanhf_fast(pre.z);
-        const float go = sigmoidf_fast(pre.w);
-        const bool active = t < len;
-        const float cn = gf * c + gi * gg;
-        const float hn = go * tanhf_fast(cn);
-        if (active) { c = cn; h = hn; }
-        if (s_abort) break;
-        if (step + 1 < T) {
-            // publish h_t: each cell thread writes its own bf16 hi and lo (2-byte stores, no LDS re-layout,
-            // no second barrier); layout [kc = unit/8][n][hl][unit%8] of this member's 1-KiB block
-            const unsigned e = (unsigned)(step >> 1) & 1u;
-            const unsigned tb = (pu & 1) ? (1u - e) : e;
-            unsigned short hi, lo;
-            split_tagged(h, tb, hi, lo);
-            const unsigned off = (unsigned)(step & 1) * SLOT + (unsigned)g * 1024u +
-                                 (unsigned)((((pu >> 3) * 16 + pn) * 2) * 16 + (pu & 7) * 2);
-            if (same_xcd) {
-                __builtin_amdgcn_raw_buffer_store_b16(hi, rsrc, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b16(lo, rsrc, off + 16, 0, 0);
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b16(hi, rsrc, off, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b16(lo, rsrc, off + 16, 0, 16);
+            if (s_abort) goto done;
+            if (w == STORER_WAVE) {
+                if (step > 0) io_store_results(step - 1);
+            } else if (w < IO_WAVE) {
+                float4 pre = xin[step % FWD_RING][tid];
+                if (step > 0) {
+                    const float* pp = &part[step & 1][pn * PROW + pu * 4];
+                    const float4 p0 = *reinterpret_cast<const float4*>(pp);
+                    const float4 p1 = *reinterpret_cast<const float4*>(pp + 16 * PROW);
+                    const float4 p2 = *reinterpret_cast<const float4*>(pp + 32 * PROW);
+                    const float4 p3 = *reinterpret_cast<const float4*>(pp + 48 * PROW);
+                    pre.x += (p0.x + p1.x) + (p2.x + p3.x);
+                    pre.y += (p0.y + p1.y) + (p2.y + p3.y);
+                    pre.z += (p0.z + p1.z) + (p2.z + p3.z);
+                    pre.w += (p0.w + p1.w) + (p2.w + p3.w);
+                }
+                const float gi = sigmoidf_fast(pre.x);
+                const float gf = sigmoidf_fast(pre.y);
+                const float gg = tanhf_fast(pre.z);
+                const float go = sigmoidf_fast(pre.w);
+                const bool active = t < len;
+                const float cn = gf * c + gi * gg;
+                const float hn = go * tanhf_fast(cn);
+                if (active) { c = cn; h = hn; }
+                if (step + 1 < T) {
+                    // publish h_t: each cell thread writes its own bf16 hi and lo (2-byte stores);
+                    // layout [kc = unit/8][n][hl][unit%8] of this member's 1-KiB block
+                    const unsigned e = (unsigned)(step >> 1) & 1u;
+                    const unsigned tb = (pu & 1) ? (1u - e) : e;
+                    unsigned short hi, lo;
+                    split_tagged(h, tb, hi, lo);
+                    const unsigned off = (unsigned)(step & 1) * SLOT + (unsigned)g * 1024u +
+                                         (unsigned)((((pu >> 3) * 16 + pn) * 2) * 16 + (pu & 7) * 2);
+                    if (same_xcd) {
+                        __builtin_amdgcn_raw_buffer_store_b16(hi, rsrc, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16(lo, rsrc, off + 16, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b16(hi, rsrc, off, 0, 16);
+                        __builtin_amdgcn_raw_buffer_store_b16(lo, rsrc, off + 16, 0, 16);
+                    }
+                }
+                // results for the backward pass / next layer: staged in LDS, written out by the I/O wave
+                rg[step & 1][tid] = active ? make_float4(gi, gf, gg, go) : make_float4(0, 0, 0, 0);
+                rc[step & 1][tid] = c;
+                rh[step & 1][tid] = active ? hn : 0.f;
             }
+            STAMP(6);
         }
-        STAMP(4);
-        STAMP(5);
-        // results for the backward pass / next layer: stored at the top of the next step
-        def_g = active ? make_float4(gi, gf, gg, go) : make_float4(0, 0, 0, 0);
-        def_c = c; def_h = active ? hn : 0.f; def_t = t;
-        STAMP(6);
-        xg = xn;
     }
-    flush_deferred();
+done:
+    __syncthreads();
+    if (w == STORER_WAVE && !s_abort && T > 0) io_store_results(T - 1);
 }
 
 // ------------------------------------------------------------------------------------------
-// backward sweep.  Same grid and ownership (member g owns units 16g..16g+15).  The recurrent
-// gradient dh_{prev}[k] = sum_r dgates[r] W_hh[r,k] is formed as a sum of 16 PARTIAL products,
-// one per member, each over the member's own 64 gate rows (K = 64): every step a workgroup
-//   1. loads the 16 partial sums addressed to its units (16 fp32 words per thread, tagged),
-//   2. finishes one (unit, utterance) cell: dgates from the saved activations,
+// backward sweep.  Same grid, ownership and wave roles.  The recurrent gradient
+// dh_{prev}[k] = sum_r dgates[r] W_hh[r,k] is formed as a sum of 16 PARTIAL products, one per
+// member, each over the member's own 64 gate rows (K = 64): every step a workgroup
+//   1. loads the 16 partial sums addressed to its units (16 fp32 words per compute thread, tagged),
+//   2. finishes one (unit, utterance) cell: dgates from the saved activations (from the I/O wave),
 //   3. multiplies its dgates (bf16 hi/lo through LDS) into all 256 outputs
-//      (16 MFMA tiles over the 4 waves, 2 k-steps x 3 split terms) and
+//      (16 MFMA tiles over the 4 compute waves, 2 k-steps x 3 split terms) and
 //   4. publishes that partial: [src g][n 16][unit 256] fp32 = 16 KiB, 4 x 16-B stores per lane.
 // Exchange read per workgroup and step: 16 KiB (a dgates all-gather would be 64 KiB).
 // ------------------------------------------------------------------------------------------
@@ -408,11 +466,15 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     if (g == G_CLUSTER) { prefetcher_loop(a, cl, dir, bg, true); return; }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = lane >> 4, n = lane & 15;      // MFMA coordinates
-    const int pu = tid & 15, pn = tid >> 4;      // cell coordinates (unit fastest: coalesced partial reads)
+    const int pu = tid & 15, pn = (tid >> 4) & 15;   // cell coordinates (unit fastest: coalesced partial reads)
     const int unit = 16 * g + pu;
     const int T = a.T, B = a.B;
 
     __shared__ __attribute__((aligned(16))) unsigned short dgl[2 * 16 * 2 * 64];   // [buf][n][hl][64 r' local]
+    __shared__ __attribute__((aligned(16))) float4 sg_[BWD_RING][256];             // saved gate activations ring, by cell id
+    __shared__ __attribute__((aligned(16))) float sct[BWD_RING][256];              // c_t ring (c_prev of step s = c_t of step s+1)
+    __shared__ __attribute__((aligned(16))) float sdy[BWD_RING][256];              // dout ring
+    __shared__ __attribute__((aligned(16))) float4 rdg[2][256];                    // results: d(pre-activation gates)
     __shared__ volatile int s_abort;
     __shared__ volatile int s_same;
     if (tid == 0) { s_abort = 0; s_same = 0; }
@@ -420,13 +482,15 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
 
     // A operand tiles: output units 16*(4w+mt)..+15 (rows), k = own gate rows r' = 64g + 32i + ..
     bf16x8 Whi[4][2], Wlo[4][2];
+    if (w < IO_WAVE) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const u32x4* wp = a.wpack + ((size_t)(dir * 16 + 4 * w + mt) * 32) * 2 * 64;
+        for (int mt = 0; mt < 4; ++mt) {
+            const u32x4* wp = a.wpack + ((size_t)(dir * 16 + 4 * w + mt) * 32) * 2 * 64;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            Whi[mt][i] = __builtin_bit_cast(bf16x8, wp[((2 * g + i) * 2 + 0) * 64 + lane]);
-            Wlo[mt][i] = __builtin_bit_cast(bf16x8, wp[((2 * g + i) * 2 + 1) * 64 + lane]);
+            for (int i = 0; i < 2; ++i) {
+                Whi[mt][i] = __builtin_bit_cast(bf16x8, wp[((2 * g + i) * 2 + 0) * 64 + lane]);
+                Wlo[mt][i] = __builtin_bit_cast(bf16x8, wp[((2 * g + i) * 2 + 1) * 64 + lane]);
+            }
         }
     }
     constexpr unsigned SLOT = 16 * 16 * 256 * 4;      // [src 16][n 16][unit 256] fp32 = 256 KiB
@@ -437,118 +501,143 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     const int bidx = bg * 16 + pn;
     const int len = (bidx < B) ? a.lengths[bidx] : 0;
     float dc = 0.f, carry = 0.f;
-    struct Saved { float4 gt; float ct, cp, dy; };
-    auto load_saved = [&](int t) {
-        Saved s; s.gt = make_float4(0, 0, 0, 0); s.ct = 0.f; s.cp = 0.f; s.dy = 0.f;
-        if (bidx < B) {
-            const size_t gi = (((size_t)t * B + bidx) * 2 + dir) * HID + unit;
-            s.gt = *reinterpret_cast<const float4*>(a.gates + gi * 4);
-            s.ct = a.cbuf[gi];
-            const int tp = dir ? t + 1 : t - 1;   // the step the forward sweep ran just before t
-            if (tp >= 0 && tp < T) s.cp = a.cbuf[(((size_t)tp * B + bidx) * 2 + dir) * HID + unit];
-            s.dy = a.dout[((size_t)t * B + bidx) * (2 * HID) + dir * HID + unit];
+
+    // ---- loader / storer: lane L serves cells 64k+L for the 16-byte gate rows and cells 4L..4L+3 for 4-byte rows
+    auto step_t = [&](int s) { return dir ? s : T - 1 - s; };
+    // 6 LDS-DMA instructions per step, ALWAYS issued (step and utterance clamped) so the counted wait is exact
+    auto loader_issue = [&](int s) {
+        const int t = step_t(s < T ? s : T - 1);
+        const int slot = s % BWD_RING;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cell = 64 * k + lane;
+            int b = bg * 16 + (cell >> 4); b = b < B ? b : B - 1;
+            dma16(a.gates + ((((size_t)t * B + b) * 2 + dir) * HID + 16 * g + (cell & 15)) * 4, &sg_[slot][64 * k]);
         }
-        return s;
+        const int cell0 = 4 * lane, u0 = 16 * g + (cell0 & 15);
+        int b = bg * 16 + (cell0 >> 4); b = b < B ? b : B - 1;
+        dma16(a.cbuf + (((size_t)t * B + b) * 2 + dir) * HID + u0, &sct[slot][0]);
+        dma16(a.dout + ((size_t)t * B + b) * (2 * HID) + dir * HID + u0, &sdy[slot][0]);
     };
-    Saved sv = load_saved(dir ? 0 : T - 1);
-
-    for (int step = 0; step < T; ++step) {
-        const int t = dir ? step : T - 1 - step;
-        if (g == 0 && tid == 0) {   // paces the prefetcher; a plain store (shared L2) unless the cluster spans XCDs
-            if (same_xcd) *reinterpret_cast<volatile unsigned*>(a.progress + cl * 32) = (unsigned)step;
-            else __hip_atomic_store(a.progress + cl * 32, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto io_store_results = [&](int s) {
+        const int t = step_t(s), par = s & 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cell = 64 * k + lane, b = bg * 16 + (cell >> 4);
+            if (b < B) *reinterpret_cast<float4*>(a.gates + ((((size_t)t * B + b) * 2 + dir) * HID + 16 * g + (cell & 15)) * 4) = rdg[par][cell];
         }
-        // next step's saved activations: L2 hits thanks to the prefetcher workgroup (see forward sweep)
-        Saved sn; sn.gt = make_float4(0, 0, 0, 0); sn.ct = sn.cp = sn.dy = 0.f;
-        if (step + 1 < T) sn = load_saved(dir ? t + 1 : t - 1);
-        float dh_rec = carry;
-
-        if (step > 0) {
-            const unsigned pbase = (unsigned)((step - 1) & 1) * SLOT + (unsigned)((pn * 256 + unit) * 4);
-            const unsigned stale_bit = (((step - 1) >> 1) & 1) ? 0x2u : 0x1u;
-            float v[16];
-            SpinGuard sg;
-            while (true) {
-                POLL_FENCE();
-                unsigned orr = 0;
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(rsrc, pbase + (unsigned)s * (16 * 256 * 4), 0, 16);
-                    orr |= u;
-                    v[s] = __uint_as_float(u);
-                }
-                if (!__any((orr & stale_bit) != 0)) break;
-                if (s_abort || !sg.keep_waiting()) { s_abort = 1; *a.err = 1; break; }
-            }
-            float s0 = 0.f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) s0 += v[s];     // fixed order: reproducible
-            dh_rec += s0;
-        }
-        const bool active = t < len;
-        const float gi = sv.gt.x, gf = sv.gt.y, gg = sv.gt.z, go = sv.gt.w;
-        const float dh = sv.dy + dh_rec;
-        const float tc = tanhf_fast(sv.ct);
-        const float dct = dh * go * (1.f - tc * tc) + dc;
-        float4 d;
-        d.x = dct * gg * gi * (1.f - gi);
-        d.y = dct * sv.cp * gf * (1.f - gf);
-        d.z = dct * gi * (1.f - gg * gg);
-        d.w = dh * tc * go * (1.f - go);
-        if (active) { dc = dct * gf; carry = 0.f; }
-        else { d = make_float4(0, 0, 0, 0); carry = dh_rec; }
-        unsigned short* dbuf = &dgl[(step & 1) * (16 * 2 * 64)];
-        {
-            unsigned short hi[4], lo[4];
-            split_plain(d.x, hi[0], lo[0]); split_plain(d.y, hi[1], lo[1]);
-            split_plain(d.z, hi[2], lo[2]); split_plain(d.w, hi[3], lo[3]);
-            unsigned short* dst = &dbuf[(pn * 2) * 64 + pu * 4];      // [n][hl][r' local = 4*pu + gate]
-            *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
-            *reinterpret_cast<uint2*>(dst + 64) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
-        }
-        __syncthreads();
-        if (s_abort) break;
-        if (step + 1 < T) {
-            bf16x8 Dhi[2], Dlo[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                Dhi[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&dbuf[(n * 2 + 0) * 64 + 32 * i + 8 * q]));
-                Dlo[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&dbuf[(n * 2 + 1) * 64 + 32 * i + 8 * q]));
-            }
-            f32x4 acc[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[mt][i], Dhi[i], acc[mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[mt][i], Dlo[i], acc[mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wlo[mt][i], Dhi[i], acc[mt], 0, 0, 0);
-            }
-            const unsigned e = (unsigned)(step >> 1) & 1u;
-            const unsigned tag = e ? 0x1u : 0x2u;       // (bit0, bit1) = (e, 1-e)
-            const unsigned obase = (unsigned)(step & 1) * SLOT + (unsigned)g * (16 * 256 * 4);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                u32x4 o;
-                o.x = (__float_as_uint(acc[mt][0]) & ~3u) | tag;
-                o.y = (__float_as_uint(acc[mt][1]) & ~3u) | tag;
-                o.z = (__float_as_uint(acc[mt][2]) & ~3u) | tag;
-                o.w = (__float_as_uint(acc[mt][3]) & ~3u) | tag;
-                // lane (q,n), tile 4w+mt: output units 16(4w+mt) + 4q .. +3 for utterance n
-                const unsigned off = obase + (unsigned)((n * 256 + 16 * (4 * w + mt) + 4 * q) * 4);
-                if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 0);
-                else          __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 16);
-            }
-        }
-        if (bidx < B) {
-            const size_t gi2 = (((size_t)t * B + bidx) * 2 + dir) * HID + unit;
-            *reinterpret_cast<float4*>(a.gates + gi2 * 4) = d;
-        }
-        sv = sn;
+    };
+    if (w == LOADER_WAVE) {
+        for (int s = 0; s < BWD_LEAD; ++s) loader_issue(s);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // rows of steps 0..BWD_LEAD-1 are in LDS
     }
+    LDS_BARRIER();
+
+    {
+        for (int step = 0; step < T; ++step) {
+            const int t = step_t(step);
+            if (g == 0 && tid == 0) {   // paces the prefetcher
+                if (same_xcd) *reinterpret_cast<volatile unsigned*>(a.progress + cl * 32) = (unsigned)step;
+                else __hip_atomic_store(a.progress + cl * 32, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            float4 d = make_float4(0, 0, 0, 0);
+            unsigned short* dbuf = &dgl[(step & 1) * (16 * 2 * 64)];
+            if (w == LOADER_WAVE) {
+                // cells of step+1 read rows(step+1) and c_t(step+2) before the NEXT barrier: keep only the two
+                // youngest steps (12 instructions) in flight
+                loader_issue(step + BWD_LEAD);
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            } else if (w < IO_WAVE) {
+                float dh_rec = carry;
+                if (step > 0) {
+                    const unsigned pbase = (unsigned)((step - 1) & 1) * SLOT + (unsigned)((pn * 256 + unit) * 4);
+                    const unsigned stale_bit = (((step - 1) >> 1) & 1) ? 0x2u : 0x1u;
+                    float v[16];
+                    SpinGuard sg;
+                    while (true) {
+                        POLL_FENCE();
+                        unsigned orr = 0;
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) {
+                            const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(rsrc, pbase + (unsigned)s * (16 * 256 * 4), 0, 16);
+                            orr |= u;
+                            v[s] = __uint_as_float(u);
+                        }
+                        if (!__any((orr & stale_bit) != 0)) break;
+                        if (s_abort || !sg.keep_waiting()) { s_abort = 1; *a.err = 1; break; }
+                    }
+                    float sum = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) sum += v[s];     // fixed order: reproducible
+                    dh_rec += sum;
+                }
+                const bool active = t < len;
+                const float4 gt = sg_[step % BWD_RING][tid];
+                const float ct = sct[step % BWD_RING][tid], dy = sdy[step % BWD_RING][tid];
+                const float cp = (step + 1 < T) ? sct[(step + 1) % BWD_RING][tid] : 0.f;
+                const float gi = gt.x, gf = gt.y, gg = gt.z, go = gt.w;
+                const float dh = dy + dh_rec;
+                const float tc = tanhf_fast(ct);
+                const float dct = dh * go * (1.f - tc * tc) + dc;
+                d.x = dct * gg * gi * (1.f - gi);
+                d.y = dct * cp * gf * (1.f - gf);
+                d.z = dct * gi * (1.f - gg * gg);
+                d.w = dh * tc * go * (1.f - go);
+                if (active) { dc = dct * gf; carry = 0.f; }
+                else { d = make_float4(0, 0, 0, 0); carry = dh_rec; }
+                {
+                    unsigned short hi[4], lo[4];
+                    split_plain(d.x, hi[0], lo[0]); split_plain(d.y, hi[1], lo[1]);
+                    split_plain(d.z, hi[2], lo[2]); split_plain(d.w, hi[3], lo[3]);
+                    unsigned short* dst = &dbuf[(pn * 2) * 64 + pu * 4];      // [n][hl][r' local = 4*pu + gate]
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
+                    *reinterpret_cast<uint2*>(dst + 64) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+                }
+                rdg[step & 1][tid] = d;      // written to HBM by the I/O wave after the barrier
+            }
+            LDS_BARRIER();
+            if (s_abort) goto done;
+            if (w == STORER_WAVE) {
+                io_store_results(step);
+            } else if (w < IO_WAVE && step + 1 < T) {
+                bf16x8 Dhi[2], Dlo[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    Dhi[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&dbuf[(n * 2 + 0) * 64 + 32 * i + 8 * q]));
+                    Dlo[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&dbuf[(n * 2 + 1) * 64 + 32 * i + 8 * q]));
+                }
+                f32x4 acc[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[mt][i], Dhi[i], acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[mt][i], Dlo[i], acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wlo[mt][i], Dhi[i], acc[mt], 0, 0, 0);
+                }
+                const unsigned e = (unsigned)(step >> 1) & 1u;
+                const unsigned tag = e ? 0x1u : 0x2u;       // (bit0, bit1) = (e, 1-e)
+                const unsigned obase = (unsigned)(step & 1) * SLOT + (unsigned)g * (16 * 256 * 4);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    u32x4 o;
+                    o.x = (__float_as_uint(acc[mt][0]) & ~3u) | tag;
+                    o.y = (__float_as_uint(acc[mt][1]) & ~3u) | tag;
+                    o.z = (__float_as_uint(acc[mt][2]) & ~3u) | tag;
+                    o.w = (__float_as_uint(acc[mt][3]) & ~3u) | tag;
+                    // lane (q,n), tile 4w+mt: output units 16(4w+mt) + 4q .. +3 for utterance n
+                    const unsigned off = obase + (unsigned)((n * 256 + 16 * (4 * w + mt) + 4 * q) * 4);
+                    if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 0);
+                    else          __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 16);
+                }
+            }
+        }
+    }
+done:
+    return;
 }
 
 // ------------------------------------------------------------------------------------------
