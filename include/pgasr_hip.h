@@ -122,6 +122,10 @@ int pgasr_reinforce_grad(const float* scores, const int32_t* path, const float* 
  *   precision 0: exact fp32 MFMA.  precision 1: each operand element is split into bf16 hi+lo while
  *   staged and the product is hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation
  *   (~1e-6 relative; ~5x the fp32 matrix rate); not combinable with norm_operand.
+ *   xcc_allow (0 or 0xFF = everywhere; precision 1 only): bit i lets workgroups that RUN on XCD i
+ *   (read from HW_REG_XCC_ID) take tiles from a global tile queue while the others exit: keeps a GEMM
+ *   that runs beside a persistent LSTM sweep off the sweep's XCDs.  Correct for any placement.
+ *   workspace: always >= pgasr_gemm_workspace_bytes (>= 256: tile counter + partial slabs).
  * ---------------------------------------------------------------------------------------- */
 size_t pgasr_gemm_workspace_bytes(int M, int N, int batch, int splitk, int sum_batches);
 int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
@@ -131,7 +135,7 @@ int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                    int batch, int sum_batches, int splitk,
                    const float* bias, const float* bias2, int act, float slope, int accumulate,
                    const float* dact_y, int norm_operand, const float* shift, const float* scale,
-                   int precision, void* workspace, size_t workspace_bytes, void* stream);
+                   int precision, int xcc_allow, void* workspace, size_t workspace_bytes, void* stream);
 
 /* column sums of X (rows x cols, leading dim ld) -> out (and out2 if non-NULL): bias gradients. */
 size_t pgasr_colsum_workspace_bytes(int rows, int cols);

@@ -44,7 +44,7 @@ SIGNATURES = {
                                  c_f32p, C.c_int, C.c_longlong, c_f32p, C.c_int, C.c_longlong,
                                  c_f32p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                  c_f32p, c_f32p, C.c_int, C.c_float, C.c_int,
-                                 c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, c_ptr, C.c_size_t, c_ptr]),
+                                 c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, c_ptr, C.c_size_t, c_ptr]),
     "pgasr_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "pgasr_colsum_f32": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int,
                                    c_ptr, C.c_size_t, c_ptr]),

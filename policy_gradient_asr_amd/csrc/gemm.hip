@@ -35,6 +35,9 @@ struct GemmArgs {
     int norm_operand;          // 0 none, 1: A = (A - shift[b])*scale[b], 2: same on B
     const float* shift; const float* scale;
     float* partial;            // if set: raw alpha*acc slabs [z][M][N]; epilogue done by reduce
+    unsigned* queue;           // queue mode (else NULL): global tile counter, zeroed before the launch
+    unsigned xcc_allow;        // queue mode: bit i set = workgroups running on XCD i (HW_REG_XCC_ID) take tiles
+    int tx, ty, tz;            // queue mode: tile counts
 };
 
 // Load an 8-float strip of a tile operand.  KCONTIG: the operand is stored with k contiguous
@@ -301,20 +304,40 @@ __device__ __forceinline__ void xstore_strip(unsigned short* hi, unsigned short*
     }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool QUEUE>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(GemmArgs g) {
     // [buffer][operand A/B][plane hi/lo][128 rows][XPITCH]
     __shared__ __attribute__((aligned(16))) unsigned short S[2][2][2][BM * XPITCH];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    int tbx, tby, z;
-    swizzled_tile(tbx, tby, z);
+    // Queue mode (used for GEMMs that run beside a persistent LSTM sweep): a workgroup that finds itself on
+    // an XCD the sweep occupies leaves at once; every other one draws ONE tile number from a global counter.
+    // Which XCD a workgroup runs on is READ (HW_REG_XCC_ID), never assumed: the masked launch is followed by
+    // an unmasked sweeper launch on the same counter that picks up whatever tiles are left (normally none),
+    // so the result is complete for any placement.
+    int tbx = 0, tby = 0, z = 0;
+    bool live = true;      // (no early return: a dead workgroup just runs an empty k range and stores nothing)
+    if (QUEUE) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xFu;
+        const bool allowed = ((g.xcc_allow >> xcc) & 1u) != 0;
+        // the tile number travels through the first word of the staging array (a second __shared__ object
+        // next to it made hipcc 7.2 fall back to a 1-wave/SIMD register allocation)
+        unsigned* mailbox = reinterpret_cast<unsigned*>(&S[0][0][0][0]);
+        if (tid == 0) *mailbox = allowed ? __hip_atomic_fetch_add(g.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+        __syncthreads();
+        const unsigned t = *mailbox;
+        __syncthreads();
+        live = t < (unsigned)g.tx * g.ty * g.tz;
+        if (live) { tbx = (int)(t % g.tx); tby = (int)((t / g.tx) % g.ty); z = (int)(t / ((unsigned)g.tx * g.ty)); }
+    } else {
+        swizzled_tile(tbx, tby, z);
+    }
     const int bidx = z / g.splitk, sidx = z % g.splitk;
     const int m0 = tby * BM, n0 = tbx * BN;
     const float* A = g.A + (size_t)bidx * g.sA;
     const float* B = g.B + (size_t)bidx * g.sB;
     const int kbeg = sidx * g.kper;
-    const int kend = min(g.K, kbeg + g.kper);
+    const int kend = live ? min(g.K, kbeg + g.kper) : kbeg;
     const bool vecA = ((g.lda & 3) == 0) && ((((size_t)A) & 15) == 0);
     const bool vecB = ((g.ldb & 3) == 0) && ((((size_t)B) & 15) == 0);
 
@@ -388,7 +411,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(GemmArgs g
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 64 + j * 32 + cl;
-            if (n >= g.N) continue;
+            if (n >= g.N || !live) continue;
             float bsum = 0.f;
             if (!g.partial) {
                 if (g.bias) bsum += g.bias[n];
@@ -483,24 +506,45 @@ __global__ __launch_bounds__(1024) void instnorm_stats_kernel(const float* __res
 
 }  // namespace
 
-static int gemm_launch(GemmArgs& g, int transA, int transB, int sum_batches, int precision, void* workspace,
+static int gemm_launch(GemmArgs& g, int transA, int transB, int sum_batches, int precision, int xcc_allow, void* workspace,
                        size_t workspace_bytes, hipStream_t st) {
     const int Z = g.batch * g.splitk;
     const bool use_partial = (g.splitk > 1) || sum_batches;
-    if (use_partial) {
-        const size_t need = (size_t)Z * g.M * g.N * sizeof(float);
+    const bool queue_mode = precision == 1 && (xcc_allow & 0xFF) != 0 && (xcc_allow & 0xFF) != 0xFF;
+    const size_t head = 256;   // the first 256 workspace bytes hold the tile counter of queue mode
+    if (use_partial || queue_mode) {
+        const size_t need = head + (use_partial ? (size_t)Z * g.M * g.N * sizeof(float) : 0);
         if (!workspace || workspace_bytes < need) return PGASR_ERR_WORKSPACE;
-        g.partial = (float*)workspace;
-    } else {
-        g.partial = nullptr;
     }
+    g.partial = use_partial ? (float*)((char*)workspace + head) : nullptr;
+    g.queue = nullptr; g.xcc_allow = 0xFFu;
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, Z);
     if (grid.y > 65535 || grid.z > 65535) return PGASR_ERR_UNSUPPORTED;
+    g.tx = (int)grid.x; g.ty = (int)grid.y; g.tz = (int)grid.z;
+    if (queue_mode) {
+        g.queue = (unsigned*)workspace; g.xcc_allow = (unsigned)xcc_allow & 0xFFu;
+        if (hipMemsetAsync(workspace, 0, head, st) != hipSuccess) return PGASR_ERR_LAUNCH;
+    }
+    const unsigned ntiles_q = grid.x * grid.y * grid.z;
+    const unsigned nallow_q = (unsigned)__builtin_popcount(g.xcc_allow & 0xFFu);
     if (precision == 1) {
-        if (!transA && !transB) PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<false, false>), grid, dim3(GEMM_THREADS), 0, st, g);
-        else if (!transA && transB) PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<false, true>), grid, dim3(GEMM_THREADS), 0, st, g);
-        else if (transA && !transB) PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<true, false>), grid, dim3(GEMM_THREADS), 0, st, g);
-        else PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<true, true>), grid, dim3(GEMM_THREADS), 0, st, g);
+        if (queue_mode) {
+            // pass 0: masked, enough workgroups that the allowed XCDs alone can cover every tile under
+            // round-robin dealing; pass 1: unmasked sweeper for any tiles left over (normally all exit at once)
+            for (int pass = 0; pass < 2; ++pass) {
+                dim3 qgrid(pass == 0 ? (ntiles_q * 8u + nallow_q - 1) / nallow_q + 8u : ntiles_q);
+                if (pass == 1) g.xcc_allow = 0xFFu;
+                if (!transA && !transB) PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<false, false, true>), qgrid, dim3(GEMM_THREADS), 0, st, g);
+                else if (!transA && transB) PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<false, true, true>), qgrid, dim3(GEMM_THREADS), 0, st, g);
+                else if (transA && !transB) PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<true, false, true>), qgrid, dim3(GEMM_THREADS), 0, st, g);
+                else PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<true, true, true>), qgrid, dim3(GEMM_THREADS), 0, st, g);
+                PGASR_CHECK_LAUNCH();
+            }
+        }
+        else if (!transA && !transB) PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<false, false, false>), grid, dim3(GEMM_THREADS), 0, st, g);
+        else if (!transA && transB) PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<false, true, false>), grid, dim3(GEMM_THREADS), 0, st, g);
+        else if (transA && !transB) PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<true, false, false>), grid, dim3(GEMM_THREADS), 0, st, g);
+        else PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<true, true, false>), grid, dim3(GEMM_THREADS), 0, st, g);
     }
     else if (!transA && !transB) PGASR_LAUNCH_KERNEL((gemm_f32_kernel<false, false>), grid, dim3(GEMM_THREADS), 0, st, g);
     else if (!transA && transB) PGASR_LAUNCH_KERNEL((gemm_f32_kernel<false, true>), grid, dim3(GEMM_THREADS), 0, st, g);
@@ -520,8 +564,8 @@ static int gemm_launch(GemmArgs& g, int transA, int transB, int sum_batches, int
 
 extern "C" size_t pgasr_gemm_workspace_bytes(int M, int N, int batch, int splitk, int sum_batches) {
     if (M <= 0 || N <= 0 || batch <= 0 || splitk <= 0) return 0;
-    if (splitk <= 1 && !sum_batches) return 0;
-    return (size_t)batch * splitk * M * N * sizeof(float);
+    if (splitk <= 1 && !sum_batches) return 256;
+    return 256 + (size_t)batch * splitk * M * N * sizeof(float);
 }
 
 extern "C" int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
@@ -531,7 +575,7 @@ extern "C" int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float
                               int batch, int sum_batches, int splitk,
                               const float* bias, const float* bias2, int act, float slope, int accumulate,
                               const float* dact_y, int norm_operand, const float* shift, const float* scale,
-                              int precision, void* workspace, size_t workspace_bytes, void* stream) {
+                              int precision, int xcc_allow, void* workspace, size_t workspace_bytes, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || splitk <= 0) return PGASR_ERR_INVALID_ARG;
     if (norm_operand < 0 || norm_operand > 2 || (norm_operand && (!shift || !scale))) return PGASR_ERR_INVALID_ARG;
     if (act < 0 || act > 1 || precision < 0 || precision > 1) return PGASR_ERR_INVALID_ARG;
@@ -546,7 +590,7 @@ extern "C" int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float
     g.kper = kper;
     g.alpha = alpha; g.bias = bias; g.bias2 = bias2; g.act = act; g.slope = slope; g.accumulate = accumulate;
     g.dact_y = dact_y; g.norm_operand = norm_operand; g.shift = shift; g.scale = scale; g.partial = nullptr;
-    return gemm_launch(g, transA, transB, sum_batches, precision, workspace, workspace_bytes, (hipStream_t)stream);
+    return gemm_launch(g, transA, transB, sum_batches, precision, xcc_allow, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" size_t pgasr_colsum_workspace_bytes(int rows, int cols) {

@@ -22,6 +22,7 @@ class grad_overlap:
     straight into the parameters' pre-allocated .grad buffers.  ``finish()`` makes the current
     stream wait for the side stream; call it after loss.backward()."""
     enabled = False
+    confine = True     # keep side-stream GEMMs off the XCDs of the concurrent LSTM sweep
     _side = None
 
     @classmethod
@@ -204,8 +205,18 @@ class BLSTMLayerFn(torch.autograd.Function):
             # says which workgroups share an XCD, not which XCD, and the two streams' dispatch offsets
             # differ -- the sweep went from 2.2 to 2.9 ms; a 1-D masked launch also ran the GEMMs
             # 13-30 % slower than the 3-D grid.  All XCDs are used.)
-            with torch.cuda.stream(side):
-                weight_grads(accumulate_into=targets)
+            # The next op on the main stream is the layer below's backward sweep, whose clusters sit (on an
+            # otherwise idle GPU) on XCDs 0..2*ceil(B/16)-1.  Keep these GEMMs off those XCDs while it runs:
+            # queue-mode launch, membership decided from the XCD each workgroup actually runs on.
+            busy = min(2 * ((B + 15) // 16), 8)
+            allow = (0xFF & ~((1 << busy) - 1)) if (ctx.needs_input_grad[0] and busy <= 4 and not ctx.has_dact) else 0
+            prev = hipops.GEMM_XCC_ALLOW
+            hipops.GEMM_XCC_ALLOW = allow if grad_overlap.confine else 0
+            try:
+                with torch.cuda.stream(side):
+                    weight_grads(accumulate_into=targets)
+            finally:
+                hipops.GEMM_XCC_ALLOW = prev
             for t_ in (dg, x, out):
                 t_.record_stream(side)
             return (dx, None, None) + (None,) * 8

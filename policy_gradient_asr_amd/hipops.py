@@ -158,13 +158,14 @@ def reinforce_grad(scores, path, coef, lengths, out=None, accumulate=False):
 # ------------------------------------------------------------------------------------------
 # dense contractions
 # ------------------------------------------------------------------------------------------
+GEMM_XCC_ALLOW = 0   # 0 = every XCD; functional.grad_overlap narrows it for side-stream GEMMs
 GEMM_PRECISION = 1   # default for the model's GEMMs: 1 = bf16x3 split MFMA, 0 = exact fp32 MFMA
 
 
 def gemm(A, B, C, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=None, alpha=1.0,
          strideA=0, strideB=0, strideC=0, batch=1, sum_batches=False, splitk=1, bias=None, bias2=None,
          act=0, slope=0.01, accumulate=False, dact_y=None, norm_operand=0, shift=None, scale=None,
-         a_off=0, b_off=0, c_off=0, precision=None):
+         a_off=0, b_off=0, c_off=0, precision=None, xcc_allow=None):
     """Raw strided GEMM on device tensors (element offsets a_off/b_off/c_off into A/B/C).
     See include/pgasr_hip.h for the contract."""
     lib = _lib.load()
@@ -179,13 +180,13 @@ def gemm(A, B, C, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=N
     ldb = ldb if ldb is not None else (K if transB else N)
     ldc = ldc if ldc is not None else N
     nbytes = lib.pgasr_gemm_workspace_bytes(M, N, batch, splitk, int(sum_batches))
-    ws = _workspace(nbytes, C.device, "gemm") if nbytes else None
+    ws = _workspace(nbytes, C.device, "gemm")
     with _timed("gemm_f32"):
       st = lib.pgasr_gemm_f32(int(transA), int(transB), M, N, K, float(alpha),
                             A.data_ptr() + 4 * a_off, lda, int(strideA), B.data_ptr() + 4 * b_off, ldb, int(strideB),
                             C.data_ptr() + 4 * c_off, ldc, int(strideC), batch, int(sum_batches), splitk,
                             _p(bias), _p(bias2), act, float(slope), int(accumulate), _p(dact_y),
-                            norm_operand, _p(shift), _p(scale), int(precision), _p(ws), ws.numel() if ws is not None else 0, _stream())
+                            norm_operand, _p(shift), _p(scale), int(precision), int(GEMM_XCC_ALLOW if xcc_allow is None else xcc_allow), _p(ws), ws.numel() if ws is not None else 0, _stream())
     _lib.check(st, "pgasr_gemm_f32")
     return C
 

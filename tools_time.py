@@ -52,3 +52,16 @@ for rnd in range(2):
             tr.step(*batch)
         torch.cuda.synchronize()
         print(f"overlap={ov}: {(time.perf_counter()-t0)*1e3/5:.2f} ms/step", flush=True)
+
+# ---- A/B: confine side-stream GEMMs to the XCDs the sweep does not use ----
+from policy_gradient_asr_amd.functional import grad_overlap
+tr.overlap_weight_grads = True
+for rnd in range(2):
+    for cf in (False, True):
+        grad_overlap.confine = cf
+        tr.step(*batch); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(5):
+            tr.step(*batch)
+        torch.cuda.synchronize()
+        print(f"confine={cf}: {(time.perf_counter()-t0)*1e3/5:.2f} ms/step", flush=True)
