@@ -121,7 +121,7 @@ int pgasr_reinforce_grad(const float* scores, const int32_t* path, const float* 
  *   the tile is loaded: the per-utterance InstanceNorm2d of model.py:37,48 fused into the affine.
  *   precision 0: exact fp32 MFMA.  precision 1: each operand element is split into bf16 hi+lo while
  *   staged and the product is hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation
- *   (~1e-6 relative; ~5x the fp32 matrix rate); not combinable with norm_operand.
+ *   (~1e-6 relative; ~5x the fp32 matrix rate).
  *   xcc_allow (0 or 0xFF = everywhere; precision 1 only): bit i lets workgroups that RUN on XCD i
  *   (read from HW_REG_XCC_ID) take tiles from a global tile queue while the others exit: keeps a GEMM
  *   that runs beside a persistent LSTM sweep off the sweep's XCDs.  Correct for any placement.

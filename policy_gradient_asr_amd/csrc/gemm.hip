@@ -378,8 +378,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(GemmArgs g
                 }
         }
     };
+    // per-utterance instance norm fused into the load of operand A (norm_operand 1) or B (2): applied after
+    // the plain load under a wave-uniform branch (unconditional sub+mul cost every GEMM ~10 %), in-range only
+    const int nrm = g.norm_operand;
+    const float nsh = nrm ? g.shift[bidx] : 0.f, nsc = nrm ? g.scale[bidx] : 1.f;
+    auto norm_strip = [&](float (&v)[16], bool kcontig, int mn_base, int mn_lim, int kb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int mn = kcontig ? mn_base + (tid >> 1) : mn_base + (tid >> 5) * 16 + i;
+            const int k = kcontig ? kb + (tid & 1) * 16 + i : kb + (tid & 31);
+            v[i] = (mn < mn_lim && k < kend) ? (v[i] - nsh) * nsc : 0.f;
+        }
+    };
 #define XLOAD(RA, RB, KB) do { xload_strip<!TA>(A, g.lda, m0, g.M, (KB), kend, tid, vecA, RA); \
-                               xload_strip<TB>(B, g.ldb, n0, g.N, (KB), kend, tid, vecB, RB); } while (0)
+                               xload_strip<TB>(B, g.ldb, n0, g.N, (KB), kend, tid, vecB, RB); \
+                               if (nrm == 1) norm_strip(RA, !TA, m0, g.M, (KB)); \
+                               else if (nrm == 2) norm_strip(RB, TB, n0, g.N, (KB)); } while (0)
 #define XSTORE(RA, RB, BUF) do { xstore_strip<!TA>(S[BUF][0][0], S[BUF][0][1], tid, RA); \
                                  xstore_strip<TB>(S[BUF][1][0], S[BUF][1][1], tid, RB); } while (0)
     if (kbeg < kend) {
@@ -579,7 +593,6 @@ extern "C" int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || splitk <= 0) return PGASR_ERR_INVALID_ARG;
     if (norm_operand < 0 || norm_operand > 2 || (norm_operand && (!shift || !scale))) return PGASR_ERR_INVALID_ARG;
     if (act < 0 || act > 1 || precision < 0 || precision > 1) return PGASR_ERR_INVALID_ARG;
-    if (precision == 1 && norm_operand) return PGASR_ERR_UNSUPPORTED;
     if ((splitk > 1 || sum_batches) && dact_y) return PGASR_ERR_INVALID_ARG;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;

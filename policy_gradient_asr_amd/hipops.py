@@ -170,7 +170,7 @@ def gemm(A, B, C, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=N
     See include/pgasr_hip.h for the contract."""
     lib = _lib.load()
     if precision is None:
-        precision = 0 if norm_operand else GEMM_PRECISION
+        precision = GEMM_PRECISION
     for t, nm in ((A, "A"), (B, "B"), (C, "C"), (bias, "bias"), (bias2, "bias2"), (dact_y, "dact_y"),
                   (shift, "shift"), (scale, "scale")):
         if t is not None:
