@@ -122,9 +122,11 @@ int pgasr_reinforce_grad(const float* scores, const int32_t* path, const float* 
  *   precision 0: exact fp32 MFMA.  precision 1: each operand element is split into bf16 hi+lo while
  *   staged and the product is hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation
  *   (~1e-6 relative; ~5x the fp32 matrix rate).
- *   xcc_allow (0 or 0xFF = everywhere; precision 1 only): bit i lets workgroups that RUN on XCD i
- *   (read from HW_REG_XCC_ID) take tiles from a global tile queue while the others exit: keeps a GEMM
- *   that runs beside a persistent LSTM sweep off the sweep's XCDs.  Correct for any placement.
+ *   xcc_busy (NULL = plain launch; precision 1 only): device array of 8 words, e.g. the busy counters a
+ *   persistent LSTM sweep keeps in its workspace (pgasr_lstm_busy_offset).  Tiles are then drawn from a
+ *   global queue and a workgroup that RUNS on XCD i (HW_REG_XCC_ID) with xcc_busy[i] != 0 takes none; an
+ *   unmasked second launch picks up any leftovers.  Keeps a GEMM off the XCDs of a concurrent sweep; the
+ *   result is complete and identical for any placement.
  *   workspace: always >= pgasr_gemm_workspace_bytes (>= 256: tile counter + partial slabs).
  * ---------------------------------------------------------------------------------------- */
 size_t pgasr_gemm_workspace_bytes(int M, int N, int batch, int splitk, int sum_batches);
@@ -135,7 +137,7 @@ int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                    int batch, int sum_batches, int splitk,
                    const float* bias, const float* bias2, int act, float slope, int accumulate,
                    const float* dact_y, int norm_operand, const float* shift, const float* scale,
-                   int precision, int xcc_allow, void* workspace, size_t workspace_bytes, void* stream);
+                   int precision, const unsigned* xcc_busy, void* workspace, size_t workspace_bytes, void* stream);
 
 /* column sums of X (rows x cols, leading dim ld) -> out (and out2 if non-NULL): bias gradients. */
 size_t pgasr_colsum_workspace_bytes(int rows, int cols);
@@ -184,6 +186,7 @@ int pgasr_lstm_unpack_grads(const float* dwih_perm, const float* dbias_perm, con
                             int accumulate, void* stream);
 size_t pgasr_lstm_workspace_bytes(int T, int B, int backward);
 int pgasr_lstm_error_offset(int B, int backward, size_t* offset);
+int pgasr_lstm_busy_offset(int B, int backward, size_t* offset);   /* 8 per-XCD busy counters (hint for pgasr_gemm_f32) */
 int pgasr_lstm_layer_fwd(float* gates, float* out, float* cbuf, const void* whh_pack_fwd,
                          const int32_t* lengths, int T, int B, int flags,
                          void* workspace, size_t workspace_bytes, void* stream);

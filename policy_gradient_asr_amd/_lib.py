@@ -44,7 +44,7 @@ SIGNATURES = {
                                  c_f32p, C.c_int, C.c_longlong, c_f32p, C.c_int, C.c_longlong,
                                  c_f32p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                  c_f32p, c_f32p, C.c_int, C.c_float, C.c_int,
-                                 c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, c_ptr, C.c_size_t, c_ptr]),
+                                 c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "pgasr_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "pgasr_colsum_f32": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int,
                                    c_ptr, C.c_size_t, c_ptr]),
@@ -55,6 +55,7 @@ SIGNATURES = {
     "pgasr_lstm_unpack_grads": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int] + [c_f32p] * 8 + [C.c_int, c_ptr]),
     "pgasr_lstm_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "pgasr_lstm_error_offset": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "pgasr_lstm_busy_offset": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "pgasr_lstm_layer_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int,
                                        c_ptr, C.c_size_t, c_ptr]),
     "pgasr_lstm_layer_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int,

@@ -36,7 +36,7 @@ struct GemmArgs {
     const float* shift; const float* scale;
     float* partial;            // if set: raw alpha*acc slabs [z][M][N]; epilogue done by reduce
     unsigned* queue;           // queue mode (else NULL): global tile counter, zeroed before the launch
-    unsigned xcc_allow;        // queue mode: bit i set = workgroups running on XCD i (HW_REG_XCC_ID) take tiles
+    const unsigned* xcc_busy;  // queue mode: [8] words; a workgroup running on XCD i (HW_REG_XCC_ID) with busy[i] != 0 takes no tile
     int tx, ty, tz;            // queue mode: tile counts
 };
 
@@ -319,7 +319,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(GemmArgs g
     bool live = true;      // (no early return: a dead workgroup just runs an empty k range and stores nothing)
     if (QUEUE) {
         const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xFu;
-        const bool allowed = ((g.xcc_allow >> xcc) & 1u) != 0;
+        const bool allowed = g.xcc_busy == nullptr ||
+                             __hip_atomic_load(g.xcc_busy + (xcc & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
         // the tile number travels through the first word of the staging array (a second __shared__ object
         // next to it made hipcc 7.2 fall back to a 1-wave/SIMD register allocation)
         unsigned* mailbox = reinterpret_cast<unsigned*>(&S[0][0][0][0]);
@@ -520,34 +521,35 @@ __global__ __launch_bounds__(1024) void instnorm_stats_kernel(const float* __res
 
 }  // namespace
 
-static int gemm_launch(GemmArgs& g, int transA, int transB, int sum_batches, int precision, int xcc_allow, void* workspace,
+static int gemm_launch(GemmArgs& g, int transA, int transB, int sum_batches, int precision, const unsigned* xcc_busy, void* workspace,
                        size_t workspace_bytes, hipStream_t st) {
     const int Z = g.batch * g.splitk;
     const bool use_partial = (g.splitk > 1) || sum_batches;
-    const bool queue_mode = precision == 1 && (xcc_allow & 0xFF) != 0 && (xcc_allow & 0xFF) != 0xFF;
+    const bool queue_mode = precision == 1 && xcc_busy != nullptr;
     const size_t head = 256;   // the first 256 workspace bytes hold the tile counter of queue mode
     if (use_partial || queue_mode) {
         const size_t need = head + (use_partial ? (size_t)Z * g.M * g.N * sizeof(float) : 0);
         if (!workspace || workspace_bytes < need) return PGASR_ERR_WORKSPACE;
     }
     g.partial = use_partial ? (float*)((char*)workspace + head) : nullptr;
-    g.queue = nullptr; g.xcc_allow = 0xFFu;
+    g.queue = nullptr; g.xcc_busy = nullptr;
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, Z);
     if (grid.y > 65535 || grid.z > 65535) return PGASR_ERR_UNSUPPORTED;
     g.tx = (int)grid.x; g.ty = (int)grid.y; g.tz = (int)grid.z;
     if (queue_mode) {
-        g.queue = (unsigned*)workspace; g.xcc_allow = (unsigned)xcc_allow & 0xFFu;
+        g.queue = (unsigned*)workspace; g.xcc_busy = xcc_busy;
         if (hipMemsetAsync(workspace, 0, head, st) != hipSuccess) return PGASR_ERR_LAUNCH;
     }
     const unsigned ntiles_q = grid.x * grid.y * grid.z;
-    const unsigned nallow_q = (unsigned)__builtin_popcount(g.xcc_allow & 0xFFu);
+
     if (precision == 1) {
         if (queue_mode) {
             // pass 0: masked, enough workgroups that the allowed XCDs alone can cover every tile under
             // round-robin dealing; pass 1: unmasked sweeper for any tiles left over (normally all exit at once)
             for (int pass = 0; pass < 2; ++pass) {
-                dim3 qgrid(pass == 0 ? (ntiles_q * 8u + nallow_q - 1) / nallow_q + 8u : ntiles_q);
-                if (pass == 1) g.xcc_allow = 0xFFu;
+                // pass 0: twice the tiles, so that half the XCDs alone can cover them; pass 1 ignores the hint
+                dim3 qgrid(pass == 0 ? 2u * ntiles_q + 8u : ntiles_q);
+                if (pass == 1) g.xcc_busy = nullptr;
                 if (!transA && !transB) PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<false, false, true>), qgrid, dim3(GEMM_THREADS), 0, st, g);
                 else if (!transA && transB) PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<false, true, true>), qgrid, dim3(GEMM_THREADS), 0, st, g);
                 else if (transA && !transB) PGASR_LAUNCH_KERNEL((gemm_bf16x3_kernel<true, false, true>), qgrid, dim3(GEMM_THREADS), 0, st, g);
@@ -589,7 +591,7 @@ extern "C" int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float
                               int batch, int sum_batches, int splitk,
                               const float* bias, const float* bias2, int act, float slope, int accumulate,
                               const float* dact_y, int norm_operand, const float* shift, const float* scale,
-                              int precision, int xcc_allow, void* workspace, size_t workspace_bytes, void* stream) {
+                              int precision, const unsigned* xcc_busy, void* workspace, size_t workspace_bytes, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || splitk <= 0) return PGASR_ERR_INVALID_ARG;
     if (norm_operand < 0 || norm_operand > 2 || (norm_operand && (!shift || !scale))) return PGASR_ERR_INVALID_ARG;
     if (act < 0 || act > 1 || precision < 0 || precision > 1) return PGASR_ERR_INVALID_ARG;
@@ -603,7 +605,7 @@ extern "C" int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float
     g.kper = kper;
     g.alpha = alpha; g.bias = bias; g.bias2 = bias2; g.act = act; g.slope = slope; g.accumulate = accumulate;
     g.dact_y = dact_y; g.norm_operand = norm_operand; g.shift = shift; g.scale = scale; g.partial = nullptr;
-    return gemm_launch(g, transA, transB, sum_batches, precision, xcc_allow, workspace, workspace_bytes, (hipStream_t)stream);
+    return gemm_launch(g, transA, transB, sum_batches, precision, xcc_busy, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" size_t pgasr_colsum_workspace_bytes(int rows, int cols) {

@@ -59,6 +59,7 @@ struct LstmArgs {
     unsigned* hello;         // [clusters][16] start-up words (XCC id of each member), zeroed per call
     unsigned* progress;      // [clusters] current step of member 0 (paces the prefetcher), zeroed per call
     int* err;                // set to 1 when a bounded wait gives up
+    unsigned* busy;          // [8] per-XCD count of clusters currently sweeping there (read by queue-mode GEMMs)
     const int* lengths;      // [B]
     int T, B, NBG, NCL8;
     int force_mode;          // 0 auto, 1 force write-through (cross-XCD safe), for tests
@@ -110,6 +111,13 @@ __device__ __forceinline__ unsigned bad4(u32x4 v, unsigned want) {
 // by the exchange protocol itself, never by this barrier.
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+__device__ __forceinline__ void release_xcd(const LstmArgs& a, int g, int tid) {
+    if (g == 0 && tid == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xFu;
+        __hip_atomic_fetch_add(a.busy + xcc, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // -1
+    }
+}
+
 struct SpinGuard {
     unsigned spins = 0; long long t0 = 0;
     // returns false when the wait has lasted longer than SPIN_TIMEOUT_TICKS
@@ -145,6 +153,8 @@ __device__ __forceinline__ bool cluster_same_xcd(const LstmArgs& a, int cl, int 
         }
         const bool same = !__any((v & 0xFu) != xcc);
         if (tid == 0) *s_flag = (same && a.force_mode == 0) ? 1 : 0;
+        // tell overlapped GEMMs which XCD this cluster occupies (a speed hint, released at kernel end)
+        if (tid == 0 && g == 0) __hip_atomic_fetch_add(a.busy + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     return *s_flag != 0;
@@ -446,6 +456,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
 done:
     __syncthreads();
     if (w == STORER_WAVE && !s_abort && T > 0) io_store_results(T - 1);
+    release_xcd(a, g, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -637,7 +648,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
         }
     }
 done:
-    return;
+    release_xcd(a, g, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -818,6 +829,7 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
     LstmArgs a;
     a.gates = gates; a.out = out; a.cbuf = cbuf; a.dout = dout; a.wpack = (const u32x4*)wpack;
     a.xbuf = (unsigned char*)(ws + l.xbuf); a.hello = (unsigned*)(ws + l.hello); a.err = (int*)(ws + l.err);
+    a.busy = (unsigned*)(ws + l.err + 64);   // 8 words inside the zeroed 256-byte head block
     a.progress = (unsigned*)(ws + l.progress);
     a.lengths = lengths; a.T = T; a.B = B; a.NBG = l.NBG; a.NCL8 = l.NCL8;
     a.force_mode = (flags & 1) ? 1 : 0;
@@ -851,5 +863,11 @@ extern "C" int pgasr_lstm_layer_bwd(float* gates, const float* out, const float*
 extern "C" int pgasr_lstm_error_offset(int B, int backward, size_t* offset) {
     if (!offset || B <= 0) return PGASR_ERR_INVALID_ARG;
     *offset = lstm_ws_layout(B, backward != 0).err;
+    return PGASR_OK;
+}
+
+extern "C" int pgasr_lstm_busy_offset(int B, int backward, size_t* offset) {
+    if (!offset || B <= 0) return PGASR_ERR_INVALID_ARG;
+    *offset = lstm_ws_layout(B, backward != 0).err + 64;
     return PGASR_OK;
 }

@@ -145,7 +145,7 @@ class BLSTMLayerFn(torch.autograd.Function):
     per-utterance lengths (packed-sequence semantics of model.py:52-55)."""
 
     @staticmethod
-    def forward(ctx, x, lengths, dact_y, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+    def forward(ctx, x, lengths, dact_y, sweep_follows, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
         T, B, I = x.shape
         x = x.contiguous()
         params = [p.contiguous() for p in (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)]
@@ -158,6 +158,7 @@ class BLSTMLayerFn(torch.autograd.Function):
         hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B)
         ctx.save_for_backward(x, lengths, gates, out, cbuf, wih_perm, pack_b, dact_y if dact_y is not None else x.new_empty(0))
         ctx.has_dact = dact_y is not None
+        ctx.sweep_follows = bool(sweep_follows)   # backward: another layer's sweep runs right after this one
         ctx.param_refs = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
         return out
 
@@ -205,24 +206,26 @@ class BLSTMLayerFn(torch.autograd.Function):
             # says which workgroups share an XCD, not which XCD, and the two streams' dispatch offsets
             # differ -- the sweep went from 2.2 to 2.9 ms; a 1-D masked launch also ran the GEMMs
             # 13-30 % slower than the 3-D grid.  All XCDs are used.)
-            # The next op on the main stream is the layer below's backward sweep, whose clusters sit (on an
-            # otherwise idle GPU) on XCDs 0..2*ceil(B/16)-1.  Keep these GEMMs off those XCDs while it runs:
-            # queue-mode launch, membership decided from the XCD each workgroup actually runs on.
-            busy = min(2 * ((B + 15) // 16), 8)
-            allow = (0xFF & ~((1 << busy) - 1)) if (ctx.needs_input_grad[0] and busy <= 4 and not ctx.has_dact) else 0
-            prev = hipops.GEMM_XCC_ALLOW
-            hipops.GEMM_XCC_ALLOW = allow if grad_overlap.confine else 0
+            # The next op on the main stream is the layer below's backward sweep.  Its clusters register the XCDs
+            # they actually run on in busy counters inside the sweep workspace; queue-mode GEMM workgroups
+            # consult those for the XCD THEY run on and stay away (measured: sweep 2.2 -> 1.8 ms).
+            main = torch.cuda.current_stream()
+            busy_ptr = hipops.lstm_busy_ptr(T, B, True, dev, stream=main) if (ctx.sweep_follows and grad_overlap.confine) else 0
+            prev = hipops.GEMM_XCC_BUSY_PTR
+            hipops.GEMM_XCC_BUSY_PTR = busy_ptr
             try:
                 with torch.cuda.stream(side):
                     weight_grads(accumulate_into=targets)
             finally:
-                hipops.GEMM_XCC_ALLOW = prev
+                hipops.GEMM_XCC_BUSY_PTR = prev
             for t_ in (dg, x, out):
                 t_.record_stream(side)
-            return (dx, None, None) + (None,) * 8
+            return (dx, None, None, None) + (None,) * 8
         gl = weight_grads()
-        return (dx, None, None, *gl)
+        return (dx, None, None, None, *gl)
 
 
-def blstm_layer(x, lengths, params, dact_y=None):
-    return BLSTMLayerFn.apply(x, lengths, dact_y, *params)
+def blstm_layer(x, lengths, params, dact_y=None, sweep_follows=False):
+    """sweep_follows: in the backward pass the sweep of the layer BELOW runs right after this layer's
+    (True for every layer but the first) -- lets the overlapped weight-gradient GEMMs stay off its XCDs."""
+    return BLSTMLayerFn.apply(x, lengths, dact_y, sweep_follows, *params)

@@ -158,14 +158,14 @@ def reinforce_grad(scores, path, coef, lengths, out=None, accumulate=False):
 # ------------------------------------------------------------------------------------------
 # dense contractions
 # ------------------------------------------------------------------------------------------
-GEMM_XCC_ALLOW = 0   # 0 = every XCD; functional.grad_overlap narrows it for side-stream GEMMs
+GEMM_XCC_BUSY_PTR = 0   # device address of a sweep's 8 busy counters (0 = plain launch); set around side-stream GEMMs
 GEMM_PRECISION = 1   # default for the model's GEMMs: 1 = bf16x3 split MFMA, 0 = exact fp32 MFMA
 
 
 def gemm(A, B, C, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=None, alpha=1.0,
          strideA=0, strideB=0, strideC=0, batch=1, sum_batches=False, splitk=1, bias=None, bias2=None,
          act=0, slope=0.01, accumulate=False, dact_y=None, norm_operand=0, shift=None, scale=None,
-         a_off=0, b_off=0, c_off=0, precision=None, xcc_allow=None):
+         a_off=0, b_off=0, c_off=0, precision=None, xcc_busy=None):
     """Raw strided GEMM on device tensors (element offsets a_off/b_off/c_off into A/B/C).
     See include/pgasr_hip.h for the contract."""
     lib = _lib.load()
@@ -186,7 +186,7 @@ def gemm(A, B, C, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=N
                             A.data_ptr() + 4 * a_off, lda, int(strideA), B.data_ptr() + 4 * b_off, ldb, int(strideB),
                             C.data_ptr() + 4 * c_off, ldc, int(strideC), batch, int(sum_batches), splitk,
                             _p(bias), _p(bias2), act, float(slope), int(accumulate), _p(dact_y),
-                            norm_operand, _p(shift), _p(scale), int(precision), int(GEMM_XCC_ALLOW if xcc_allow is None else xcc_allow), _p(ws), ws.numel() if ws is not None else 0, _stream())
+                            norm_operand, _p(shift), _p(scale), int(precision), int(GEMM_XCC_BUSY_PTR if xcc_busy is None else xcc_busy), _p(ws), ws.numel() if ws is not None else 0, _stream())
     _lib.check(st, "pgasr_gemm_f32")
     return C
 
@@ -336,3 +336,18 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=5e-4, betas=(0.9, 0.999
     _lib.check(lib.pgasr_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), int(step),
                                    float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
                                    _stream()), "pgasr_adam_step")
+
+
+def lstm_busy_ptr(T, B, backward, device, stream=None):
+    """Device address of the per-XCD busy counters inside the sweep workspace used on ``stream``
+    (default: current stream) -- the hint queue-mode GEMMs read."""
+    import ctypes
+    lib = _lib.load()
+    off = ctypes.c_size_t(0)
+    _lib.check(lib.pgasr_lstm_busy_offset(B, int(backward), ctypes.byref(off)), "pgasr_lstm_busy_offset")
+    if stream is None:
+        ws = _lstm_ws(T, B, backward, device)
+    else:
+        with torch.cuda.stream(stream):
+            ws = _lstm_ws(T, B, backward, device)
+    return ws.data_ptr() + off.value

@@ -69,7 +69,8 @@ class Encoder(nn.Module):
         if training:                                   # nn.Dropout(), model.py:45,51
             h = Fh.DropoutFn.apply(h, self.drop.p, self.dropout_seed, self._next_drop_offset())
         for l in range(3):
-            h = Fh.blstm_layer(h, lengths, self._layer_params(l), dact_y=y if (l == 0 and fuse) else None)
+            h = Fh.blstm_layer(h, lengths, self._layer_params(l), dact_y=y if (l == 0 and fuse) else None,
+                               sweep_follows=(l > 0))
             if training and l < 2:                     # nn.LSTM(dropout=0.3), model.py:42: outputs of layers 0,1
                 h = Fh.DropoutFn.apply(h, self.blstm.dropout, self.dropout_seed, self._next_drop_offset())
         return h, lengths

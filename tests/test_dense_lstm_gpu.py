@@ -40,6 +40,28 @@ def test_gemm_layouts(tA, tB, M, N, K, precision, tol):
     assert rel_err(C2.cpu(), want2) < tol
 
 
+@pytest.mark.parametrize("busy_mask", [0x00, 0x0F, 0xA5, 0xFE, 0xFF])
+def test_gemm_queue_mode_is_placement_independent(busy_mask):
+    """Queue mode (pgasr_gemm_f32 xcc_busy != NULL): whichever XCDs are declared busy -- none, half, all but
+    one, or all (then the unmasked second launch does everything) -- the result is bit-identical to the plain
+    launch, for a weight-gradient shaped TN product with batch-sum slabs and accumulation."""
+    from policy_gradient_asr_amd import hipops
+    g = torch.Generator().manual_seed(7)
+    M, N, K = 1024, 512, 3000
+    A = torch.randn(K, M, generator=g).to(DEV)
+    B = torch.randn(K, N, generator=g).to(DEV)
+    base = torch.randn(M, N, generator=g).to(DEV)
+    want = base.clone()
+    hipops.gemm(A, B, want, M, N, K, transA=True, splitk=4, accumulate=True, precision=1)
+    busy = torch.tensor([(busy_mask >> i) & 1 for i in range(8)], dtype=torch.int32, device=DEV)
+    got = base.clone()
+    hipops.gemm(A, B, got, M, N, K, transA=True, splitk=4, accumulate=True, precision=1, xcc_busy=busy.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    ref = base.double().cpu() + A.double().cpu().t() @ B.double().cpu()
+    assert rel_err(got.cpu(), ref) < 1e-5
+
+
 def test_instnorm_affine_fwd_bwd():
     from policy_gradient_asr_amd import functional as Fh
     B, F, T, N = 3, 80, 50, 512
