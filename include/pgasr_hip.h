@@ -187,6 +187,10 @@ int pgasr_lstm_unpack_grads(const float* dwih_perm, const float* dbias_perm, con
 size_t pgasr_lstm_workspace_bytes(int T, int B, int backward);
 int pgasr_lstm_error_offset(int B, int backward, size_t* offset);
 int pgasr_lstm_busy_offset(int B, int backward, size_t* offset);   /* 8 per-XCD busy counters (hint for pgasr_gemm_f32) */
+/* Holds `stream` until any of words[0..count) is non-zero or timeout_us (<= 100000) has passed: put in front of
+ * GEMMs that are to run BESIDE a sweep, so that the sweep's workgroups are dispatched first (a large grid
+ * enqueued ahead of the sweep delays it by the whole GEMM).  A hint only: never affects results. */
+int pgasr_stream_gate(const unsigned* words, int count, int timeout_us, void* stream);
 int pgasr_lstm_layer_fwd(float* gates, float* out, float* cbuf, const void* whh_pack_fwd,
                          const int32_t* lengths, int T, int B, int flags,
                          void* workspace, size_t workspace_bytes, void* stream);

@@ -871,3 +871,26 @@ extern "C" int pgasr_lstm_busy_offset(int B, int backward, size_t* offset) {
     *offset = lstm_ws_layout(B, backward != 0).err + 64;
     return PGASR_OK;
 }
+
+namespace {
+// One wave that holds a stream back until a sweep has registered itself (any busy counter != 0) or the
+// time-out passes: gives "sweep first, GEMMs second" dispatch order across two streams.
+__global__ void __launch_bounds__(64) stream_gate_kernel(const unsigned* words, int count, long long timeout_ticks) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    for (;;) {
+        unsigned any = 0;
+        for (int i = 0; i < count; ++i) any |= __hip_atomic_load(words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        POLL_FENCE();
+        if (any != 0u || wall_clock64() - t0 > timeout_ticks) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+}  // namespace
+
+extern "C" int pgasr_stream_gate(const unsigned* words, int count, int timeout_us, void* stream) {
+    if (!words || count <= 0 || count > 64 || timeout_us < 0 || timeout_us > 100000) return PGASR_ERR_INVALID_ARG;
+    PGASR_LAUNCH_KERNEL(stream_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, count, (long long)timeout_us * 100);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}

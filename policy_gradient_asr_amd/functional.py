@@ -24,6 +24,7 @@ class grad_overlap:
     enabled = False
     confine = True     # keep side-stream GEMMs off the XCDs of the concurrent LSTM sweep
     _side = None
+    _pending = []      # (ready event, closure) of the layer above, issued right AFTER the next sweep is launched
 
     @classmethod
     def side_stream(cls):
@@ -32,7 +33,34 @@ class grad_overlap:
         return cls._side
 
     @classmethod
+    def flush(cls, busy_ptr=0, launched_after=None):
+        """Issue the deferred weight-gradient GEMMs on the side stream.  Called right after a sweep kernel
+        has been launched: a kernel with a large grid enqueued BEFORE the sweep holds up the dispatch of
+        everything behind it, on any stream (rocprof: the sweep's 5 us memset waited 616 us for the GEMM
+        in front of it), so the order of enqueueing is sweep first, GEMMs second."""
+        if not cls._pending:
+            return
+        side = cls.side_stream()
+        prev = hipops.GEMM_XCC_BUSY_PTR
+        hipops.GEMM_XCC_BUSY_PTR = busy_ptr if cls.confine else 0
+        try:
+            with torch.cuda.stream(side):
+                for ready, fn in cls._pending:
+                    side.wait_event(ready)
+                if launched_after is not None and busy_ptr:
+                    # enqueue order says nothing about dispatch order when the host runs ahead: wait for the point
+                    # on the main stream just before the sweep, then for the sweep's clusters to register
+                    side.wait_event(launched_after)
+                    hipops.stream_gate(busy_ptr)
+                for ready, fn in cls._pending:
+                    fn()
+        finally:
+            hipops.GEMM_XCC_BUSY_PTR = prev
+            cls._pending = []
+
+    @classmethod
     def finish(cls):
+        cls.flush()
         if cls._side is not None:
             torch.cuda.current_stream().wait_stream(cls._side)
 
@@ -169,8 +197,17 @@ class BLSTMLayerFn(torch.autograd.Function):
         G = 2 * 4 * HID
         dev = x.device
         dout = dout.contiguous()
+        if grad_overlap.enabled:
+            before = torch.cuda.Event()
+            before.record()
         hipops.lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B)   # gates := dgates
         dg = gates
+        if grad_overlap.enabled:
+            # the layer above left its weight-gradient GEMMs for now: they run beside THIS sweep, whose clusters
+            # register the XCDs they occupy in busy counters that the queue-mode GEMM workgroups consult
+            grad_overlap.flush(hipops.lstm_busy_ptr(T, B, True, dev), launched_after=before)
+            swept = torch.cuda.Event()
+            swept.record()
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, B, I, dtype=torch.float32, device=dev)
@@ -201,23 +238,9 @@ class BLSTMLayerFn(torch.autograd.Function):
         targets = [p.grad for p in ctx.param_refs]
         if grad_overlap.enabled and all(t is not None and t.is_contiguous() for t in targets):
             side = grad_overlap.side_stream()
-            side.wait_stream(torch.cuda.current_stream())
-            # (Confining these GEMMs to "the other" XCD slots was tried and measured WORSE: blockIdx % 8
-            # says which workgroups share an XCD, not which XCD, and the two streams' dispatch offsets
-            # differ -- the sweep went from 2.2 to 2.9 ms; a 1-D masked launch also ran the GEMMs
-            # 13-30 % slower than the 3-D grid.  All XCDs are used.)
-            # The next op on the main stream is the layer below's backward sweep.  Its clusters register the XCDs
-            # they actually run on in busy counters inside the sweep workspace; queue-mode GEMM workgroups
-            # consult those for the XCD THEY run on and stay away (measured: sweep 2.2 -> 1.8 ms).
-            main = torch.cuda.current_stream()
-            busy_ptr = hipops.lstm_busy_ptr(T, B, True, dev, stream=main) if (ctx.sweep_follows and grad_overlap.confine) else 0
-            prev = hipops.GEMM_XCC_BUSY_PTR
-            hipops.GEMM_XCC_BUSY_PTR = busy_ptr
-            try:
-                with torch.cuda.stream(side):
-                    weight_grads(accumulate_into=targets)
-            finally:
-                hipops.GEMM_XCC_BUSY_PTR = prev
+            grad_overlap._pending.append((swept, lambda: weight_grads(accumulate_into=targets)))
+            if not ctx.sweep_follows:
+                grad_overlap.flush()       # nothing left to hide behind: go now
             for t_ in (dg, x, out):
                 t_.record_stream(side)
             return (dx, None, None, None) + (None,) * 8

@@ -351,3 +351,9 @@ def lstm_busy_ptr(T, B, backward, device, stream=None):
         with torch.cuda.stream(stream):
             ws = _lstm_ws(T, B, backward, device)
     return ws.data_ptr() + off.value
+
+
+def stream_gate(words_ptr, count=8, timeout_us=60):
+    """Hold the current stream until a sweep has registered in the busy counters at ``words_ptr``."""
+    lib = _lib.load()
+    _lib.check(lib.pgasr_stream_gate(words_ptr, count, timeout_us, _stream()), "pgasr_stream_gate")

@@ -8,7 +8,7 @@ from policy_gradient_asr_amd.train_step import PolicyGradientTrainer
 from bench import synth_batch, V, F
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(dev).eval()
+m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(dev); m.train(os.environ.get("PGASR_TT_TRAIN","0")=="1")
 tr = PolicyGradientTrainer(m, seed=1)
 batch = synth_batch(dev, 1)
 for i in range(2):
