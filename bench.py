@@ -153,11 +153,13 @@ def main():
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         peak = 157.3
         traffic = None   # HBM bytes per launch of that kernel from the committed PMC passes (profiles/)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_lstm_pmc.json")) as fi:
-                traffic = json.load(fi)["kernels"][name]["hbm_bytes_per_launch"]
-        except Exception:  # noqa: BLE001 - the file is optional evidence, never required to run
-            traffic = None
+        for fname in ("r01_pmc.json",):     # written by tools/pmc_summary.py
+            try:
+                with open(os.path.join(ROOT, "profiles", fname)) as fi:
+                    traffic = json.load(fi)["kernels"][name]["hbm_bytes_per_launch"]
+                break
+            except Exception:  # noqa: BLE001 - the file is optional evidence, never required to run
+                traffic = None
         out = {
             "metric": "utterances/sec (B=32,T=1000,F=80) policy-grad step, 1/2/4/8 MI355X",
             "value": value, "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
