@@ -140,6 +140,21 @@ int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                    int precision, const unsigned* xcc_busy, void* workspace, size_t workspace_bytes, void* stream);
 
 /* column sums of X (rows x cols, leading dim ld) -> out (and out2 if non-NULL): bias gradients. */
+/* Activation x weight GEMM with the weight PRE-SPLIT into bf16 hi/lo planes (csrc/gemm_dma.hip):
+ *   C[M,N] = A[M,K] * W[N,K]^T (+ bias[n]) (* (dact_y[m,n] > 0 ? 1 : slope))
+ * Replaces the same torch calls as pgasr_gemm_f32 for the two big shapes of the path: the LSTM input
+ * projections (model.py:39-44) and their input gradients.  Same 3-term bf16 split / fp32 accumulate as
+ * pgasr_gemm_f32(precision=1); tiles are moved by LDS-DMA three stages deep.
+ * pgasr_split_bf16_planes: src (rows x cols fp32, leading dim ld) -> dense planes hi, lo of
+ *   (rows x cols) bf16, or (cols x rows) when transpose != 0; x = hi + lo to ~2^-17 relative.
+ * pgasr_gemm_x3w_f32 needs K % 32 == 0, N % 128 == 0, lda % 4 == 0 and 16-byte aligned A / planes, else
+ *   PGASR_ERR_UNSUPPORTED (use pgasr_gemm_f32).  dact_y (optional) has C's shape and leading dim. */
+int pgasr_split_bf16_planes(const float* src, int rows, int cols, int ld, int transpose,
+                            unsigned short* hi, unsigned short* lo, void* stream);
+int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
+                       const unsigned short* Wlo, float* C, int ldc, const float* bias,
+                       const float* dact_y, float slope, void* stream);
+
 size_t pgasr_colsum_workspace_bytes(int rows, int cols);
 int pgasr_colsum_f32(const float* X, int rows, int cols, int ld, float* out, float* out2, int accumulate,
                      void* workspace, size_t workspace_bytes, void* stream);

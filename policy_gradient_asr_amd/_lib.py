@@ -45,6 +45,9 @@ SIGNATURES = {
                                  c_f32p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                  c_f32p, c_f32p, C.c_int, C.c_float, C.c_int,
                                  c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, c_ptr, c_ptr, C.c_size_t, c_ptr]),
+    "pgasr_split_bf16_planes": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr]),
+    "pgasr_gemm_x3w_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_ptr, c_ptr, c_f32p, C.c_int,
+                                     c_f32p, c_f32p, C.c_float, c_ptr]),
     "pgasr_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "pgasr_colsum_f32": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int,
                                    c_ptr, C.c_size_t, c_ptr]),

@@ -1,0 +1,261 @@
+// Activation x weight GEMM of the path's two big shapes -- the LSTM input projections
+// X(T*B, in) W_ih^T (model.py:39-44) and their input gradients dG(T*B, 8H) W_ih -- as
+//     C[M,N] = A[M,K] * W[N,K]^T  (+ bias[n]) (* leaky'(dact_y[m,n]))
+// with fp32-grade accuracy at bf16 MFMA rate (3-term split hi*hi + hi*lo + lo*hi, fp32 accumulate,
+// like gemm.hip's bf16x3 kernel) and a load path built around LDS-DMA:
+//
+//   * W arrives PRE-SPLIT into bf16 hi / lo planes [N][K] (pgasr_split_bf16_planes, once per step
+//     per weight: 4 MB), so its tiles go global -> LDS untouched;
+//   * A stays fp32 in HBM (it is an activation: its producer writes it once) and its raw fp32
+//     tile goes global -> LDS untouched as well; the hi/lo split happens on the MFMA fragment a lane
+//     has just read (v_cvt_pk_bf16_f32), in the shadow of the previous MFMAs;
+//   * no staging registers at all: every tile is moved by global_load_lds_dwordx4, three stages
+//     deep (two tiles in flight across the single raw s_barrier per k-tile, counted s_waitcnt
+//     vmcnt(6); cdna_hip_programming.md "Pipelining across barriers"), which the register-staged
+//     kernel could not afford (it spent 42 % of its wave cycles in s_waitcnt);
+//   * 256x128x32 tile, 8 waves as 4(M) x 2(N), 64x64 per wave = 2x2 v_mfma_f32_32x32x16_bf16
+//     tiles x 3 terms x 2 k-steps = 24 MFMAs per wave per k-tile; 144 KB of LDS, one workgroup
+//     per CU, two waves per SIMD;
+//   * LDS images are lane-linear per wave-instruction (a DMA constraint), so bank conflicts are
+//     removed by swizzling the per-lane SOURCE address and the fragment read address alike:
+//     A rows are 128 B (8 chunks of 16 B, chunk ^= (row>>1)&7), plane rows 64 B (4 chunks,
+//     chunk ^= (row>>2)&3): any 16 consecutive rows at one logical chunk cover all 16 slots of a
+//     256-byte bank row.
+//
+// Preconditions (else PGASR_ERR_UNSUPPORTED; callers fall back to pgasr_gemm_f32):
+// K % 32 == 0, N % 128 == 0, lda % 4 == 0, 16-byte aligned A / planes.  M is arbitrary (rows are
+// clamped on load and masked on store).
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int TM = 256, TN = 128, TK = 32, NST = 3, DMA_THREADS = 512;
+constexpr int A_BYTES = TM * TK * 4;                 // 32 KB raw fp32
+constexpr int P_BYTES = TN * TK * 2;                 // 8 KB per bf16 plane
+constexpr int STAGE_BYTES = A_BYTES + 2 * P_BYTES;   // 48 KB
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+struct DmaGemmArgs {
+    const float* A; const unsigned short* Whi; const unsigned short* Wlo; float* C;
+    int M, N, K, lda, ldc;
+    const float* bias; const float* dact_y; float slope;
+};
+
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                     (void __attribute__((address_space(3)))*)lds_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi_pk, unsigned& lo_pk) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    const bf2 h = __builtin_convertvector((f2){x0, x1}, bf2);
+    hi_pk = __builtin_bit_cast(unsigned, h);
+    const float h0 = __uint_as_float(hi_pk << 16), h1 = __uint_as_float(hi_pk & 0xFFFF0000u);
+    const bf2 l = __builtin_convertvector((f2){x0 - h0, x1 - h1}, bf2);
+    lo_pk = __builtin_bit_cast(unsigned, l);
+}
+
+// XCD-aware tile order (same remap as gemm.hip): each XCD walks a contiguous run of the
+// n-fastest tile order, so the column tiles that share an A panel share an L2.
+__device__ __forceinline__ void swizzled_tile(int& bx, int& by) {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned nwg = gx * gy;
+    const unsigned L = blockIdx.x + gx * blockIdx.y;
+    const unsigned q = nwg / 8, r = nwg % 8;
+    const unsigned xcd = L % 8, i = L / 8;
+    const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    bx = (int)(t % gx); by = (int)(t / gx);
+}
+
+// Fragments of one 16-deep k-step straight out of LDS: 2 row tiles x 2 chunks of fp32 A, 2 column tiles x (hi, lo)
+// of W.  Inline asm because hipcc puts s_waitcnt vmcnt(0) in front of any ds_read it can see after an LDS-DMA
+// (checked in the .s, with run-time and with compile-time stage indices), draining the tile meant to stay in flight.
+struct RawFrag { u32x4_t a[2][2]; u32x4_t bh[2], bl[2]; };
+__device__ __forceinline__ void frag_read(RawFrag& r, unsigned pa0, unsigned pa1, unsigned pb0, unsigned pb1) {
+    static_assert(P_BYTES == 8192, "plane offset is spelled in the asm below");
+    asm volatile("ds_read_b128 %0, %8\n\t"
+                 "ds_read_b128 %1, %9\n\t"
+                 "ds_read_b128 %2, %10\n\t"
+                 "ds_read_b128 %3, %11\n\t"
+                 "ds_read_b128 %4, %12\n\t"
+                 "ds_read_b128 %5, %12 offset:8192\n\t"
+                 "ds_read_b128 %6, %13\n\t"
+                 "ds_read_b128 %7, %13 offset:8192"
+                 : "=&v"(r.a[0][0]), "=&v"(r.a[0][1]), "=&v"(r.a[1][0]), "=&v"(r.a[1][1]),
+                   "=&v"(r.bh[0]), "=&v"(r.bl[0]), "=&v"(r.bh[1]), "=&v"(r.bl[1])
+                 : "v"(pa0), "v"(pa0 ^ 16u), "v"(pa1), "v"(pa1 ^ 16u), "v"(pb0), "v"(pb1)
+                 : "memory");
+}
+__device__ __forceinline__ void frag_wait(RawFrag& r) {     // claims the registers the reads above are filling
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(r.a[0][0]), "+v"(r.a[0][1]), "+v"(r.a[1][0]), "+v"(r.a[1][1]),
+                   "+v"(r.bh[0]), "+v"(r.bl[0]), "+v"(r.bh[1]), "+v"(r.bl[1])
+                 :: "memory");
+}
+__device__ __forceinline__ void split8(const u32x4_t& r0, const u32x4_t& r1, bf16x8_t& hi, bf16x8_t& lo) {
+    u32x4_t h, l;
+    unsigned a, b;
+    split2(__uint_as_float(r0.x), __uint_as_float(r0.y), a, b); h.x = a; l.x = b;
+    split2(__uint_as_float(r0.z), __uint_as_float(r0.w), a, b); h.y = a; l.y = b;
+    split2(__uint_as_float(r1.x), __uint_as_float(r1.y), a, b); h.z = a; l.z = b;
+    split2(__uint_as_float(r1.z), __uint_as_float(r1.w), a, b); h.w = a; l.w = b;
+    hi = __builtin_bit_cast(bf16x8_t, h); lo = __builtin_bit_cast(bf16x8_t, l);
+}
+
+__global__ __launch_bounds__(DMA_THREADS) void gemm_x3w_kernel(DmaGemmArgs g) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];   // the ONLY LDS object
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    int tbx, tby;
+    swizzled_tile(tbx, tby);
+    const int m0 = tby * TM, n0 = tbx * TN;
+    const int nk = g.K / TK;
+
+    // ---- per-lane DMA sources (k offset added per tile) ----
+    const float* pa[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = j * DMA_THREADS + tid, row = i >> 3, cp = i & 7, c = cp ^ ((row >> 1) & 7);
+        int gm = m0 + row; gm = gm < g.M ? gm : g.M - 1;
+        pa[j] = g.A + (size_t)gm * g.lda + c * 4;
+    }
+    const unsigned short *ph, *pl;
+    {
+        const int row = tid >> 2, cp = tid & 3, c = cp ^ ((row >> 2) & 3);
+        const size_t o = (size_t)(n0 + row) * g.K + c * 8;
+        ph = g.Whi + o; pl = g.Wlo + o;
+    }
+    auto issue = [&](int kt, int stage) {      // ALWAYS 6 wave-instructions (k clamped), so the counted wait is exact
+        const int k0 = (kt < nk ? kt : nk - 1) * TK;
+        unsigned char* sa = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16(pa[j] + k0, sa + (j * DMA_THREADS + w * 64) * 16);
+        dma16(ph + k0, sa + A_BYTES + w * 64 * 16);
+        dma16(pl + k0, sa + A_BYTES + P_BYTES + w * 64 * 16);
+    };
+
+    // ---- per-lane fragment read offsets inside a stage ----
+    const int fr = lane & 31, fh = lane >> 5;
+    unsigned offA[2][2], offB[2][2];     // [k-step][row tile / column tile]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wm * 64 + i * 32 + fr, sw = (row >> 1) & 7;
+            const int n = wn * 64 + i * 32 + fr, swb = (n >> 2) & 3;
+            offA[ks][i] = (unsigned)(row * 128 + (((ks * 4 + fh * 2) ^ sw) * 16));   // second chunk: ^ 16
+            offB[ks][i] = (unsigned)(A_BYTES + n * 64 + (((ks * 2 + fh) ^ swb) * 16));
+        }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // One barrier per k-tile: "my pieces of tile kt have landed" (counted vmcnt: tile kt+1 may still fly) -> barrier
+    // (everyone's pieces visible; nobody reads stage (kt+2)%3 = (kt-1)%3 any more) -> issue tile kt+2 -> read, split,
+    // multiply tile kt.  (Tried and measured slower on the path's shapes: two wave groups half a k-tile apart with
+    // two barriers per tile, 339/285 us against 285/225 us; 4 waves of 128x64 with the split hand-placed in the MFMA
+    // shadows, 382/270 us -- one LDS-DMA wave-instruction costs its wave ~100 issue cycles, so fewer waves issue
+    // the same DMA more slowly.)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    issue(0, 0);
+    issue(1, 1);
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue(kt + 2, stage >= 1 ? stage - 1 : NST - 1);       // (stage + 2) % 3
+        const unsigned sbase = lds0 + (unsigned)stage * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            RawFrag r;
+            frag_read(r, sbase + offA[ks][0], sbase + offA[ks][1], sbase + offB[ks][0], sbase + offB[ks][1]);
+            frag_wait(r);
+            bf16x8_t ah[2], al[2];
+            split8(r.a[0][0], r.a[0][1], ah[0], al[0]);
+            split8(r.a[1][0], r.a[1][1], ah[1], al[1]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, r.bh[j]), bl = __builtin_bit_cast(bf16x8_t, r.bl[j]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+                }
+        }
+        stage = stage + 1 < NST ? stage + 1 : 0;
+    }
+
+    // epilogue: 32x32 accumulator layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int cl = lane & 31, rq = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + cl;
+            const float bsum = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+                if (m >= g.M) continue;
+                float v = acc[i][j][r] + bsum;
+                if (g.dact_y) v *= (g.dact_y[(size_t)m * g.ldc + n] > 0.f ? 1.f : g.slope);
+                g.C[(size_t)m * g.ldc + n] = v;
+            }
+        }
+}
+
+// fp32 (rows x cols, leading dim ld) -> dense bf16 hi / lo planes; transpose: planes are (cols x rows)
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int rows, int cols, int ld,
+                                                           int transpose, unsigned short* __restrict__ hi,
+                                                           unsigned short* __restrict__ lo) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)rows * cols) return;
+    int r, c;
+    if (transpose) { c = (int)(idx / rows); r = (int)(idx % rows); }     // output index = c*rows + r
+    else { r = (int)(idx / cols); c = (int)(idx % cols); }
+    unsigned h, l;
+    split2(src[(size_t)r * ld + c], 0.f, h, l);
+    hi[idx] = (unsigned short)h;
+    lo[idx] = (unsigned short)l;
+}
+
+}  // namespace
+
+extern "C" int pgasr_split_bf16_planes(const float* src, int rows, int cols, int ld, int transpose,
+                                       unsigned short* hi, unsigned short* lo, void* stream) {
+    if (!src || !hi || !lo || rows <= 0 || cols <= 0 || ld < cols) return PGASR_ERR_INVALID_ARG;
+    const size_t total = (size_t)rows * cols;
+    PGASR_LAUNCH_KERNEL(split_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                        src, rows, cols, ld, transpose, hi, lo);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
+
+extern "C" int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
+                                  const unsigned short* Wlo, float* C, int ldc, const float* bias,
+                                  const float* dact_y, float slope, void* stream) {
+    if (!A || !Whi || !Wlo || !C || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N) return PGASR_ERR_INVALID_ARG;
+    if ((K % TK) || (N % TN) || (lda & 3) || (((size_t)A) & 15) || (((size_t)Whi) & 15) || (((size_t)Wlo) & 15))
+        return PGASR_ERR_UNSUPPORTED;
+    const unsigned gy = (unsigned)((M + TM - 1) / TM);
+    if (gy > 65535u) return PGASR_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)NST * STAGE_BYTES;   // 144 KB of the CU's 160 KB: opt in per call (idempotent, no state kept)
+    if (hipFuncSetAttribute((const void*)gemm_x3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PGASR_ERR_LAUNCH;
+    DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, dact_y, slope};
+    PGASR_LAUNCH_KERNEL(gemm_x3w_kernel, dim3((unsigned)(N / TN), gy), dim3(DMA_THREADS), lds, (hipStream_t)stream, g);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}

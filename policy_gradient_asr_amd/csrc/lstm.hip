@@ -388,6 +388,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
                 for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
+                    if ((a.diag & 256) && i == 1) break;      // diagnostic: half the MFMA work (results invalid)
 #pragma unroll
                     for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[m][i], Hhi[i], acc[m], 0, 0, 0);
 #pragma unroll
@@ -420,13 +421,14 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
                     pre.z += (p0.z + p1.z) + (p2.z + p3.z);
                     pre.w += (p0.w + p1.w) + (p2.w + p3.w);
                 }
-                const float gi = sigmoidf_fast(pre.x);
-                const float gf = sigmoidf_fast(pre.y);
-                const float gg = tanhf_fast(pre.z);
-                const float go = sigmoidf_fast(pre.w);
+                const bool cheap = (a.diag & 512) != 0;       // diagnostic: no transcendentals (results invalid)
+                const float gi = cheap ? pre.x * 0.5f : sigmoidf_fast(pre.x);
+                const float gf = cheap ? pre.y * 0.5f : sigmoidf_fast(pre.y);
+                const float gg = cheap ? pre.z * 0.5f : tanhf_fast(pre.z);
+                const float go = cheap ? pre.w * 0.5f : sigmoidf_fast(pre.w);
                 const bool active = t < len;
                 const float cn = gf * c + gi * gg;
-                const float hn = go * tanhf_fast(cn);
+                const float hn = go * (cheap ? cn * 0.5f : tanhf_fast(cn));
                 if (active) { c = cn; h = hn; }
                 if (step + 1 < T) {
                     // publish h_t: each cell thread writes its own bf16 hi and lo (2-byte stores);
@@ -833,7 +835,7 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
     a.progress = (unsigned*)(ws + l.progress);
     a.lengths = lengths; a.T = T; a.B = B; a.NBG = l.NBG; a.NCL8 = l.NCL8;
     a.force_mode = (flags & 1) ? 1 : 0;
-    a.diag = (flags >> 8) & 0xFF;
+    a.diag = (flags >> 8) & 0xFFFF;
     a.stamps = (long long*)(ws + l.stamps);
 #ifdef PGASR_LSTM_STAMPS
     if (T > STAMP_MAX_T) return PGASR_ERR_UNSUPPORTED;

@@ -180,7 +180,10 @@ class BLSTMLayerFn(torch.autograd.Function):
         wih_perm, bias_perm, pack_f, pack_b = hipops.lstm_pack(params, I)
         G = 2 * 4 * HID
         gates = torch.empty(T, B, G, dtype=torch.float32, device=x.device)
-        hipops.gemm(x, wih_perm, gates, M=T * B, N=G, K=I, transB=True, bias=bias_perm)
+        if hipops.gemm_x3w_ok(T * B, G, I):      # LDS-DMA kernel, weight pre-split into bf16 hi/lo planes
+            hipops.gemm_x3w(x, hipops.split_planes(wih_perm), gates, T * B, G, I, bias=bias_perm)
+        else:
+            hipops.gemm(x, wih_perm, gates, M=T * B, N=G, K=I, transB=True, bias=bias_perm)
         out = torch.empty(T, B, 2 * HID, dtype=torch.float32, device=x.device)
         cbuf = torch.empty(T, B, 2 * HID, dtype=torch.float32, device=x.device)
         hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B)
@@ -211,8 +214,12 @@ class BLSTMLayerFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, B, I, dtype=torch.float32, device=dev)
-            hipops.gemm(dg, wih_perm, dx, M=T * B, N=I, K=G, dact_y=dact_y if ctx.has_dact else None,
-                        slope=LEAKY_SLOPE)
+            if hipops.gemm_x3w_ok(T * B, I, G):
+                hipops.gemm_x3w(dg, hipops.split_planes(wih_perm, transpose=True), dx, T * B, I, G,
+                                dact_y=dact_y if ctx.has_dact else None, slope=LEAKY_SLOPE)
+            else:
+                hipops.gemm(dg, wih_perm, dx, M=T * B, N=I, K=G, dact_y=dact_y if ctx.has_dact else None,
+                            slope=LEAKY_SLOPE)
         def weight_grads(accumulate_into=None):
             dwih = torch.empty(G, I, dtype=torch.float32, device=dev)
             hipops.gemm(dg, x, dwih, M=G, N=I, K=T * B, transA=True, lda=G, splitk=_pick_splitk(G, I, T * B))

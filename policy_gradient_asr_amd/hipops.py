@@ -191,6 +191,44 @@ def gemm(A, B, C, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=N
     return C
 
 
+def split_planes(w, transpose=False):
+    """fp32 matrix (rows, cols) -> bf16 (hi, lo) planes (int16 storage) of shape (rows, cols), or
+    (cols, rows) with ``transpose``: the pre-split weight operand of ``gemm_x3w``."""
+    lib = _lib.load()
+    _req(w, torch.float32, "w")
+    if w.dim() != 2 or w.stride(1) != 1:
+        raise _lib.PgasrError("split_planes wants a row-major 2-D tensor")
+    rows, cols = w.shape
+    shape = (cols, rows) if transpose else (rows, cols)
+    hi = torch.empty(shape, dtype=torch.int16, device=w.device)
+    lo = torch.empty(shape, dtype=torch.int16, device=w.device)
+    st = lib.pgasr_split_bf16_planes(w.data_ptr(), rows, cols, w.stride(0), int(transpose), hi.data_ptr(), lo.data_ptr(), _stream())
+    _lib.check(st, "pgasr_split_bf16_planes")
+    return hi, lo
+
+
+def gemm_x3w_ok(M, N, K, lda=None):
+    """Shapes the LDS-DMA kernel takes (else use ``gemm``)."""
+    lda = K if lda is None else lda
+    return K % 32 == 0 and N % 128 == 0 and lda % 4 == 0 and M > 0
+
+
+def gemm_x3w(A, planes, C, M, N, K, lda=None, ldc=None, bias=None, dact_y=None, slope=0.01):
+    """C[M,N] = A[M,K] @ W[N,K]^T (+bias) (*leaky'(dact_y)); W given as ``split_planes`` output."""
+    lib = _lib.load()
+    hi, lo = planes
+    for t, nm in ((A, "A"), (C, "C"), (bias, "bias"), (dact_y, "dact_y")):
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32):
+            raise _lib.PgasrError(f"gemm_x3w operand {nm} must be a float32 GPU tensor")
+    if tuple(hi.shape) != (N, K) or tuple(lo.shape) != (N, K) or hi.dtype != torch.int16 or not hi.is_contiguous() or not lo.is_contiguous():
+        raise _lib.PgasrError("gemm_x3w planes must be contiguous int16 (N, K)")
+    with _timed("gemm_f32"):
+        st = lib.pgasr_gemm_x3w_f32(M, N, K, A.data_ptr(), K if lda is None else lda, hi.data_ptr(), lo.data_ptr(),
+                                    C.data_ptr(), N if ldc is None else ldc, _p(bias), _p(dact_y), float(slope), _stream())
+    _lib.check(st, "pgasr_gemm_x3w_f32")
+    return C
+
+
 def colsum(X, rows, cols, ld, out, out2=None, accumulate=False):
     lib = _lib.load()
     nbytes = lib.pgasr_colsum_workspace_bytes(rows, cols)

@@ -40,6 +40,40 @@ def test_gemm_layouts(tA, tB, M, N, K, precision, tol):
     assert rel_err(C2.cpu(), want2) < tol
 
 
+@pytest.mark.parametrize("M,N,K,with_bias,with_dact", [
+    (300, 128, 32, True, False),        # one k-tile, ragged M inside one row tile
+    (1000, 256, 96, True, True),        # 3 k-tiles (one per stage), ragged last row tile, both epilogues
+    (513, 384, 160, False, True),       # 5 k-tiles: the 3-stage ring wraps
+    (4096, 512, 2048, False, False),    # dX shape of the path (K = 8H)
+])
+def test_gemm_x3w_lds_dma(M, N, K, with_bias, with_dact):
+    """pgasr_gemm_x3w_f32 (LDS-DMA tiles, pre-split weight planes) against fp64, and against the
+    register-staged bf16x3 kernel it replaces on the big shapes."""
+    from policy_gradient_asr_amd import hipops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.1
+    bias = torch.randn(N, generator=g) if with_bias else None
+    y = torch.randn(M, N, generator=g) if with_dact else None
+    want = A.double() @ W.double().t()
+    if with_bias:
+        want = want + bias.double()
+    if with_dact:
+        want = want * torch.where(y > 0, 1.0, 0.01).double()
+    planes = hipops.split_planes(W.to(DEV))
+    hi = (planes[0].cpu().to(torch.int32) << 16).view(torch.float32)
+    lo = (planes[1].cpu().to(torch.int32) << 16).view(torch.float32)
+    assert rel_err(hi.double() + lo.double(), W) < 2e-5          # x = hi + lo to ~2^-17
+    C = torch.full((M, N), float("nan"), device=DEV)
+    hipops.gemm_x3w(A.to(DEV), planes, C, M, N, K, bias=None if bias is None else bias.to(DEV),
+                    dact_y=None if y is None else y.to(DEV), slope=0.01)
+    assert rel_err(C.cpu(), want) < 3e-5
+    # transposed planes: W given as (K, N)
+    planes_t = hipops.split_planes(W.t().contiguous().to(DEV), transpose=True)
+    assert torch.equal(planes_t[0], planes[0]) and torch.equal(planes_t[1], planes[1])
+    assert hipops.gemm_x3w_ok(M, N, K) and not hipops.gemm_x3w_ok(M, N + 1, K) and not hipops.gemm_x3w_ok(M, N, K + 8)
+
+
 @pytest.mark.parametrize("busy_mask", [0x00, 0x0F, 0xA5, 0xFE, 0xFF])
 def test_gemm_queue_mode_is_placement_independent(busy_mask):
     """Queue mode (pgasr_gemm_f32 xcc_busy != NULL): whichever XCDs are declared busy -- none, half, all but

@@ -61,7 +61,7 @@ int main() {
     unsigned char* buf; long long* cyc;
     hipMalloc(&buf, 8 * 2 * 16384); hipMalloc(&cyc, 64);
     const int steps = 3000;
-    for (int mode : {0, 1}) for (int ncl : {1, 4}) for (int work : {0, 1000}) {
+    for (int mode : {1}) for (int ncl : {4}) for (int work : {0, 250, 500, 1000, 1500, 2000, 3000}) {
         hipMemsetD32((hipDeviceptr_t)buf, 1, 8 * 2 * 16384 / 4);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);

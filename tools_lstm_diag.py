@@ -28,6 +28,6 @@ def run(flags, bwd=False):
     e1.record(); torch.cuda.synchronize()
     hipops.LSTM_FLAGS = 0
     return e0.elapsed_time(e1) / 3
-for name, fl in (("normal", 0), ("no bulk stores", 1 << 8), ("no xproj prefetch", 2 << 8), ("neither", 3 << 8), ("no prefetcher WG", 8 << 8), ("xproj load ahead of polls (old)", 64 << 8), ("prefetcher streams unrelated lines", 4 << 8), ("prefetcher ahead=1, 1/4 volume (B=4 rows)", ((1 << 5) | 0) << 8), ("prefetcher ahead=1", (1 << 5) << 8), ("prefetcher ahead=2", (2 << 5) << 8), ("prefetcher ahead=3", (3 << 5) << 8), ("prefetcher polls only (no loads)", 16 << 8), ("no prefetcher WG, no xproj prefetch", 10 << 8), ("prefetch from a fixed (cached) row", 4 << 8), ("write-through", 1)):
+for name, fl in (("normal", 0), ("no stores+no loads", 3 << 8), ("no stores/loads/prefetcher", 11 << 8), ("no stores/loads + half MFMA + cheap", (3 | 768) << 8), ("all off incl prefetcher", (11 | 768) << 8)):
     print(f"fwd {name:20s}: {run(fl):.3f} ms", flush=True)
 print(f"bwd normal: {run(0, True):.3f} ms")

@@ -27,8 +27,11 @@ print("XCC id per cluster member (rows = clusters):")
 print((hello & 0xF).tolist())
 st = ws[nb - 4096 * 64: nb].view(torch.int64).view(4096, 8)[:T].cpu().double()
 d = st[5:T - 5]
-names = ["begin->loads valid", "MFMA + partial write", "barrier 1", "sum+cell+hs write", "barrier 2", "store+bulk"]
+segs = [(0, 1, "poll: h_{t-1} words valid"), (1, 2, "MFMA + partial write"), (2, 3, "LDS barrier"), (3, 6, "sum + cell + publish")]
 tot = (d[1:, 0] - d[:-1, 0]).mean()
-print(f"cycles per step: {tot:.0f}")
-for i, nme in enumerate(names):
-    print(f"  {nme:28s} {(d[:, i + 1] - d[:, i]).mean():8.0f}  (min {(d[:, i + 1] - d[:, i]).min():.0f}, max {(d[:, i + 1] - d[:, i]).max():.0f})")
+print(f"cycles per step (100 MHz wall clock x?): {tot:.0f}")
+for i, j, nme in segs:
+    x = d[:, j] - d[:, i]
+    print(f"  {nme:28s} {x.mean():8.0f}  (min {x.min():.0f}, p50 {x.median():.0f}, max {x.max():.0f})")
+x = d[1:, 0] - d[:-1, 6]
+print(f"  {'loop back (loader/progress)':28s} {x.mean():8.0f}  (min {x.min():.0f}, p50 {x.median():.0f}, max {x.max():.0f})")
