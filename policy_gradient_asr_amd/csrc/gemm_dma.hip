@@ -162,10 +162,15 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_x3w_kernel(DmaGemmArgs g) {
 
     // One barrier per k-tile: "my pieces of tile kt have landed" (counted vmcnt: tile kt+1 may still fly) -> barrier
     // (everyone's pieces visible; nobody reads stage (kt+2)%3 = (kt-1)%3 any more) -> issue tile kt+2 -> read, split,
-    // multiply tile kt.  (Tried and measured slower on the path's shapes: two wave groups half a k-tile apart with
-    // two barriers per tile, 339/285 us against 285/225 us; 4 waves of 128x64 with the split hand-placed in the MFMA
-    // shadows, 382/270 us -- one LDS-DMA wave-instruction costs its wave ~100 issue cycles, so fewer waves issue
-    // the same DMA more slowly.)
+    // multiply tile kt.  Measured on the path's shapes (NT M=32000,N=2048,K=512 / NN M=32000,N=512,K=2048, same
+    // process; the register-staged bf16x3 kernel of gemm.hip: 327 / 317 us): this form 288 / 229 us.  Variants that
+    // were built, passed the same tests and were SLOWER: all 16 fragment reads of a k-tile issued up front
+    // (315 / 266); two wave groups half a k-tile apart, two barriers per tile, MFMA phase against load phase
+    // (339 / 285); 4 waves of 128x64 with the split hand-placed in the MFMA shadows (382 / 270); 4 dedicated loader
+    // waves beside the 8 compute waves (308 / 265).  rocprof (profiles/r01_gemm_pmc.txt): no LDS bank conflicts, MFMA
+    // pipe 35 % busy, VALU 28 %, per k-tile the CU moves 48 KB by DMA and 128 KB of fragment reads through LDS -- MFMA,
+    // LDS, VALU and the load path are all within 2x of each other, so no single reordering wins; the next step is a
+    // bf16-plane activation format written by the producers (pure bf16 GEMM over 3K, 128x64 per wave).
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     issue(0, 0);
     issue(1, 1);

@@ -20,4 +20,7 @@ C = torch.empty(M, N, device=dev); dX = torch.empty(M, K, device=dev)
 t1 = timeit(lambda: hipops.gemm_x3w(X, pl, C, M, N, K))
 t2 = timeit(lambda: hipops.gemm_x3w(dG, plt, dX, M, K, N))
 fl = 2.0 * M * N * K / 1e9
-print(f"dbg={os.environ.get('PGASR_GEMM_DBG','0')}: xproj NT {t1*1e3:.0f} us ({fl/t1:.0f} TF)  dX NN {t2*1e3:.0f} us ({fl/t2:.0f} TF)", flush=True)
+t3 = timeit(lambda: hipops.gemm(X, W, C, M, N, K, transB=True, precision=1))
+t4 = timeit(lambda: hipops.gemm(dG, W, dX, M, K, N, precision=1))
+print(f"register-staged bf16x3: xproj NT {t3*1e3:.0f} us  dX NN {t4*1e3:.0f} us", flush=True)
+print(f"LDS-DMA x3w: xproj NT {t1*1e3:.0f} us ({fl/t1:.0f} TF)  dX NN {t2*1e3:.0f} us ({fl/t2:.0f} TF)", flush=True)
