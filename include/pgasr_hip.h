@@ -65,6 +65,27 @@ int pgasr_ctc_loss_grad(const float* log_probs, const int32_t* targets,
                         float* nll, float* grad_logits,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* The gradient pass of pgasr_ctc_loss_grad on its own, over the lattice that an earlier
+ * pgasr_ctc_loss_grad(..., grad_logits = NULL, ...) call with the same T, B, V, Lmax left in `workspace`
+ * (so the lattice can run on another stream beside the kernels that produce pg_coef). */
+int pgasr_ctc_grad_from_lattice(const float* log_probs, const int32_t* input_lengths,
+                                const int32_t* target_lengths, int T, int B, int V, int Lmax, int blank,
+                                const float* utt_scale, const float* pg_coef, const int32_t* pg_path,
+                                float* grad_logits, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Rewards and gradient coefficients (policy_grad.py:4-16 intent):
+ *   dist [2B]: edit distances of the greedy paths, then of the sampled paths (pgasr_edit_distance);
+ *   R = -dist / max(L,1);  pg_coef = lam * inv_global_batch * (R_sample - R_greedy);
+ *   utt_scale = inv_global_batch / max(L,1).
+ * pgasr_pg_loss_value: terms[b] = nll[b]*utt_scale[b] - pg_coef[b] * sum_{t<input_lengths[b]} log_probs[t,b,path[t,b]]
+ *   (pg_coef and path both NULL: CTC only); the objective's value is sum_b terms[b].  Deterministic. */
+int pgasr_pg_rewards(const int32_t* dist, const int32_t* target_lengths, int B, float lam,
+                     float inv_global_batch, float* R_greedy, float* R_sample, float* pg_coef,
+                     float* utt_scale, void* stream);
+int pgasr_pg_loss_value(const float* log_probs, const int32_t* path, const int32_t* input_lengths,
+                        const float* nll, const float* utt_scale, const float* pg_coef,
+                        int T, int B, int V, float* terms, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * A9 / A12  per-frame best label and sampled label.
  *   scores (T,B,V) fp32 logits or log-probs (softmax is shift invariant).

@@ -26,6 +26,11 @@ SIGNATURES = {
     "pgasr_ctc_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "pgasr_ctc_loss_grad": (C.c_int, [c_f32p, c_i32p, c_i32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_ptr, C.c_size_t, c_ptr]),
+    "pgasr_ctc_grad_from_lattice": (C.c_int, [c_f32p, c_i32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              c_f32p, c_f32p, c_i32p, c_f32p, c_ptr, C.c_size_t, c_ptr]),
+    "pgasr_pg_rewards": (C.c_int, [c_i32p, c_i32p, C.c_int, C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_ptr]),
+    "pgasr_pg_loss_value": (C.c_int, [c_f32p, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
+                                      c_f32p, c_ptr]),
     "pgasr_frame_argmax_sample": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32,
                                             c_i32p, c_i32p, c_ptr]),
     "pgasr_ctc_collapse": (C.c_int, [c_i32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, c_ptr]),

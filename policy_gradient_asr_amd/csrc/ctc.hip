@@ -284,3 +284,29 @@ extern "C" int pgasr_ctc_loss_grad(const float* log_probs, const int32_t* target
     }
     return PGASR_OK;
 }
+
+// Second half of pgasr_ctc_loss_grad on its own: the gradient pass over a lattice that an earlier
+// pgasr_ctc_loss_grad(..., grad_logits = NULL, ...) call with the SAME shapes left in `workspace`.
+// Lets the host run the lattice (a 64-workgroup serial chain) on one stream beside the sampling /
+// decode / edit-distance kernels whose rewards the gradient needs.
+extern "C" int pgasr_ctc_grad_from_lattice(const float* log_probs, const int32_t* input_lengths,
+                                           const int32_t* target_lengths, int T, int B, int V, int Lmax, int blank,
+                                           const float* utt_scale, const float* pg_coef, const int32_t* pg_path,
+                                           float* grad_logits, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!log_probs || !input_lengths || !target_lengths || !grad_logits) return PGASR_ERR_INVALID_ARG;
+    if (T <= 0 || B <= 0 || V <= 0 || Lmax < 0 || blank < 0 || blank >= V) return PGASR_ERR_INVALID_ARG;
+    if ((pg_coef == nullptr) != (pg_path == nullptr)) return PGASR_ERR_INVALID_ARG;
+    const int Smax = 2 * Lmax + 1;
+    if (Smax > CTC_SMAX || V > CTC_VMAX) return PGASR_ERR_UNSUPPORTED;
+    CtcWs ws;
+    const size_t need = ctc_ws_layout(T, B, V, Smax, &ws, (char*)workspace);
+    if (!workspace || workspace_bytes < need) return PGASR_ERR_WORKSPACE;
+    const long long waves = (long long)T * B;
+    const int wpb = 4;
+    const unsigned blocks = (unsigned)((waves + wpb - 1) / wpb);
+    PGASR_LAUNCH_KERNEL(ctc_grad_kernel, dim3(blocks), dim3(64 * wpb), 0, (hipStream_t)stream,
+                       log_probs, input_lengths, target_lengths, T, B, V,
+                       Lmax > 0 ? Lmax : 1, Smax, blank, ws, utt_scale, pg_coef, pg_path, grad_logits);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}

@@ -116,6 +116,47 @@ __global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __re
     if (lane < V) y[r * V + lane] = v - lse;
 }
 
+// Rewards of the greedy (baseline) and sampled paths from their edit distances, and the per-utterance
+// coefficients the fused CTC + REINFORCE gradient takes (policy_grad.py:4-16 intent):
+//   R = -ED / max(L,1);  pg_coef = lam/Bg * (R_s - R_g);  utt_scale = 1 / (Bg * max(L,1))
+__global__ __launch_bounds__(256) void pg_rewards_kernel(const int32_t* __restrict__ dist, const int32_t* __restrict__ tg_len,
+                                                         int B, float lam, float inv_bg, float* __restrict__ R_g,
+                                                         float* __restrict__ R_s, float* __restrict__ coef,
+                                                         float* __restrict__ utt_scale) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const int L = tg_len[b];
+    const float Lf = (float)(L > 1 ? L : 1);
+    const float rg = -(float)dist[b] / Lf, rs = -(float)dist[B + b] / Lf;
+    R_g[b] = rg; R_s[b] = rs;
+    coef[b] = (lam * inv_bg) * (rs - rg);
+    utt_scale[b] = inv_bg / Lf;
+}
+
+// Value of the objective per utterance: nll_b * utt_scale_b - coef_b * sum_{t < T_b} log p(path[t,b]).
+// One workgroup per utterance, fixed-order reduction (deterministic).
+__global__ __launch_bounds__(256) void pg_loss_value_kernel(const float* __restrict__ lp, const int32_t* __restrict__ path,
+                                                            const int32_t* __restrict__ in_len, const float* __restrict__ nll,
+                                                            const float* __restrict__ utt_scale, const float* __restrict__ coef,
+                                                            int T, int B, int V, float* __restrict__ terms) {
+    __shared__ float red[256];
+    const int b = blockIdx.x;
+    const int Tb = min(in_len[b], T);
+    float s = 0.f;
+    if (path && coef)
+        for (int t = threadIdx.x; t < Tb; t += 256) {
+            const int k = path[(size_t)t * B + b];
+            s += lp[((size_t)t * B + b) * V + k];
+        }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) terms[b] = nll[b] * utt_scale[b] - (coef ? coef[b] * red[0] : 0.f);
+}
+
 }  // namespace
 
 extern "C" int pgasr_log_softmax_rows(const float* logits, long long rows, int V, float* log_probs, void* stream) {
@@ -160,6 +201,27 @@ extern "C" int pgasr_reinforce_grad(const float* scores, const int32_t* path, co
     const unsigned blocks = (unsigned)((rows + 3) / 4);
     PGASR_LAUNCH_KERNEL(reinforce_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        scores, path, coef, lengths, rows, B, V, accumulate, grad);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
+
+extern "C" int pgasr_pg_rewards(const int32_t* dist, const int32_t* target_lengths, int B, float lam,
+                                float inv_global_batch, float* R_greedy, float* R_sample, float* pg_coef,
+                                float* utt_scale, void* stream) {
+    if (!dist || !target_lengths || !R_greedy || !R_sample || !pg_coef || !utt_scale || B <= 0) return PGASR_ERR_INVALID_ARG;
+    PGASR_LAUNCH_KERNEL(pg_rewards_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       dist, target_lengths, B, lam, inv_global_batch, R_greedy, R_sample, pg_coef, utt_scale);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
+
+extern "C" int pgasr_pg_loss_value(const float* log_probs, const int32_t* path, const int32_t* input_lengths,
+                                   const float* nll, const float* utt_scale, const float* pg_coef,
+                                   int T, int B, int V, float* terms, void* stream) {
+    if (!log_probs || !input_lengths || !nll || !utt_scale || !terms || T <= 0 || B <= 0 || V <= 0) return PGASR_ERR_INVALID_ARG;
+    if ((pg_coef == nullptr) != (path == nullptr)) return PGASR_ERR_INVALID_ARG;
+    PGASR_LAUNCH_KERNEL(pg_loss_value_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream,
+                       log_probs, path, input_lengths, nll, utt_scale, pg_coef, T, B, V, terms);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }

@@ -100,6 +100,65 @@ def ctc_loss_grad(log_probs, targets, input_lengths, target_lengths, blank=0, ut
     return nll, grad
 
 
+def ctc_lattice(log_probs, targets, input_lengths, target_lengths, blank=0):
+    """First half of ``ctc_loss_grad``: alpha/beta lattice only.  Returns (nll (B,), handle); the handle goes to
+    ``ctc_grad_from_lattice`` (which may run on another stream once this one's work is ordered before it)."""
+    lib = _lib.load()
+    _req(log_probs, torch.float32, "log_probs")
+    T, B, V = log_probs.shape
+    _req(targets, torch.int32, "targets"); _req(input_lengths, torch.int32, "input_lengths")
+    _req(target_lengths, torch.int32, "target_lengths")
+    Lmax = targets.shape[1] if targets.dim() == 2 else 0
+    if Lmax == 0:
+        targets = torch.zeros(B, 1, dtype=torch.int32, device=log_probs.device)
+    nbytes = lib.pgasr_ctc_workspace_bytes(T, B, V, Lmax)
+    ws = _workspace(nbytes, log_probs.device, "ctc")
+    nll = torch.empty(B, dtype=torch.float32, device=log_probs.device)
+    st = lib.pgasr_ctc_loss_grad(_p(log_probs), _p(targets), _p(input_lengths), _p(target_lengths),
+                                 T, B, V, Lmax, blank, None, None, None, _p(nll), None, _p(ws), ws.numel(), _stream())
+    _lib.check(st, "pgasr_ctc_loss_grad")
+    return nll, (ws, Lmax, blank)
+
+
+def ctc_grad_from_lattice(log_probs, input_lengths, target_lengths, handle, utt_scale=None, pg_coef=None, pg_path=None):
+    lib = _lib.load()
+    ws, Lmax, blank = handle
+    T, B, V = log_probs.shape
+    _req(utt_scale, torch.float32, "utt_scale"); _req(pg_coef, torch.float32, "pg_coef"); _req(pg_path, torch.int32, "pg_path")
+    grad = torch.empty_like(log_probs)
+    st = lib.pgasr_ctc_grad_from_lattice(_p(log_probs), _p(input_lengths), _p(target_lengths), T, B, V, Lmax, blank,
+                                         _p(utt_scale), _p(pg_coef), _p(pg_path), _p(grad), _p(ws), ws.numel(), _stream())
+    _lib.check(st, "pgasr_ctc_grad_from_lattice")
+    return grad
+
+
+def pg_rewards(dist, target_lengths, lam, inv_global_batch):
+    """dist (2B,) int32 [greedy..., sampled...] -> (R_greedy, R_sample, pg_coef, utt_scale), each (B,) fp32."""
+    lib = _lib.load()
+    _req(dist, torch.int32, "dist"); _req(target_lengths, torch.int32, "target_lengths")
+    B = target_lengths.numel()
+    if dist.numel() != 2 * B:
+        raise _lib.PgasrError("pg_rewards wants 2*B distances")
+    out = torch.empty(4, B, dtype=torch.float32, device=dist.device)
+    st = lib.pgasr_pg_rewards(_p(dist), _p(target_lengths), B, float(lam), float(inv_global_batch),
+                              out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _stream())
+    _lib.check(st, "pgasr_pg_rewards")
+    return out[0], out[1], out[2], out[3]
+
+
+def pg_loss_value(log_probs, path, input_lengths, nll, utt_scale, pg_coef):
+    """Per-utterance value of the objective (see include/pgasr_hip.h); sum() it for the loss."""
+    lib = _lib.load()
+    T, B, V = log_probs.shape
+    _req(log_probs, torch.float32, "log_probs"); _req(path, torch.int32, "path"); _req(nll, torch.float32, "nll")
+    _req(utt_scale, torch.float32, "utt_scale"); _req(pg_coef, torch.float32, "pg_coef")
+    terms = torch.empty(B, dtype=torch.float32, device=log_probs.device)
+    st = lib.pgasr_pg_loss_value(_p(log_probs), _p(path), _p(input_lengths), _p(nll), _p(utt_scale), _p(pg_coef),
+                                 T, B, V, _p(terms), _stream())
+    _lib.check(st, "pgasr_pg_loss_value")
+    return terms
+
+
 def frame_argmax_sample(scores, seed=0, offset=0, want_greedy=True, want_sample=True):
     lib = _lib.load()
     _req(scores, torch.float32, "scores")

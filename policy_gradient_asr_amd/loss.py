@@ -35,28 +35,31 @@ class PGCTCLossFn(torch.autograd.Function):
     for the sampled (R_s) and greedy (R_g, baseline) paths; Bg = global batch (all ranks).
     Returns (loss, stats) where stats = (nll (B), R_s (B), R_g (B)) detached."""
 
+    _lattice_stream = None
+
     @staticmethod
     def forward(ctx, logits, in_len, targets, tg_len, lam, seed, offset, global_batch, blank):
         T, B, V = logits.shape
         dev = logits.device
         lp = hipops.log_softmax_rows(logits.contiguous())
+        # The alpha/beta lattice (a 64-workgroup serial chain, ~0.5 ms at T=1000) needs only lp and the targets: it runs
+        # on a side stream beside sampling, collapse, edit distance and the reward arithmetic, which the gradient pass
+        # then joins.
+        main = torch.cuda.current_stream()
+        side = PGCTCLossFn._lattice_stream or torch.cuda.Stream()
+        PGCTCLossFn._lattice_stream = side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            nll, lattice = hipops.ctc_lattice(lp, targets, in_len, tg_len, blank=blank)
         greedy, sample = hipops.frame_argmax_sample(lp, seed=seed, offset=offset)
-        paths = torch.stack((greedy, sample), dim=0).contiguous()            # (2,T,B)
-        tokens, tok_len = hipops.ctc_collapse(paths, in_len, blank=blank)    # (2,B,T), (2,B)
-        ref2 = torch.cat((targets, targets), dim=0).contiguous()
-        rl2 = torch.cat((tg_len, tg_len), dim=0).contiguous()
-        dist = hipops.edit_distance(ref2, rl2, tokens.view(2 * B, T), tok_len.view(2 * B).contiguous())
-        Lf = tg_len.clamp(min=1).to(torch.float32)
-        R_g = -dist[:B].to(torch.float32) / Lf
-        R_s = -dist[B:].to(torch.float32) / Lf
-        inv_bg = 1.0 / float(global_batch)
-        coef = (lam * inv_bg) * (R_s - R_g)
-        utt_scale = inv_bg / Lf
-        nll, grad = hipops.ctc_loss_grad(lp, targets, in_len, tg_len, blank=blank, utt_scale=utt_scale.contiguous(),
-                                         pg_coef=coef.contiguous(), pg_path=sample)
-        tmask = (torch.arange(T, device=dev)[:, None] < in_len[None, :])
-        lps = lp.gather(2, sample.long().unsqueeze(-1)).squeeze(-1) * tmask
-        loss = (nll * utt_scale).sum() - (coef * lps.sum(dim=0)).sum()
+        paths = torch.stack((greedy, sample), dim=0)                          # (2,T,B)
+        tokens, tok_len = hipops.ctc_collapse(paths, in_len, blank=blank)     # (2,B,T), (2,B)
+        dist = hipops.edit_distance(targets.repeat(2, 1), tg_len.repeat(2), tokens.view(2 * B, T), tok_len.view(2 * B))
+        R_g, R_s, coef, utt_scale = hipops.pg_rewards(dist, tg_len, lam, 1.0 / float(global_batch))
+        main.wait_stream(side)
+        nll.record_stream(main)
+        grad = hipops.ctc_grad_from_lattice(lp, in_len, tg_len, lattice, utt_scale=utt_scale, pg_coef=coef, pg_path=sample)
+        loss = hipops.pg_loss_value(lp, sample, in_len, nll, utt_scale, coef).sum()
         ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(nll, R_s, R_g)
         return loss, nll, R_s, R_g

@@ -106,6 +106,56 @@ def test_ctc_fused_reinforce_term(ops, dev):
     torch.testing.assert_close(g_all, g_ctc + g_pg, rtol=1e-5, atol=1e-6)
 
 
+def test_ctc_split_lattice_then_grad_is_the_same_call(ops, dev):
+    """pgasr_ctc_loss_grad(grad=NULL) + pgasr_ctc_grad_from_lattice == the one-call form, bit for bit, with the lattice
+    on another stream than the gradient pass (how loss.py runs it)."""
+    T, B, V, L = 120, 5, 29, 11
+    logits, targets, il, tl = _ctc_case(T, B, V, L, seed=21)
+    lp = torch.log_softmax(logits, 2).to(dev)
+    targets, il, tl = targets.to(dev), il.to(dev), tl.to(dev)
+    _, path = ops.frame_argmax_sample(lp, seed=3, want_greedy=False)
+    coef = torch.linspace(-1, 1, B, device=dev)
+    us = torch.linspace(0.1, 0.5, B, device=dev)
+    nll1, g1 = ops.ctc_loss_grad(lp, targets, il, tl, utt_scale=us, pg_coef=coef, pg_path=path)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        nll2, handle = ops.ctc_lattice(lp, targets, il, tl)
+    torch.cuda.current_stream().wait_stream(side)
+    g2 = ops.ctc_grad_from_lattice(lp, il, tl, handle, utt_scale=us, pg_coef=coef, pg_path=path)
+    torch.cuda.synchronize()
+    assert torch.equal(nll1, nll2) and torch.equal(g1, g2)
+
+
+def test_pg_rewards_and_loss_value(ops, dev):
+    """pgasr_pg_rewards / pgasr_pg_loss_value against the oracle's arithmetic (numpy fp64)."""
+    T, B, V = 90, 6, 29
+    g = torch.Generator().manual_seed(4)
+    lp = torch.log_softmax(torch.randn(T, B, V, generator=g), 2)
+    path = torch.randint(0, V, (T, B), generator=g, dtype=torch.int32)
+    il = torch.tensor([90, 77, 1, 50, 90, 13], dtype=torch.int32)
+    tl = torch.tensor([5, 0, 1, 9, 3, 7], dtype=torch.int32)          # a zero-length target: divisor clamps to 1
+    dist = torch.randint(0, 40, (2 * B,), generator=g, dtype=torch.int32)
+    nll = torch.rand(B, generator=g) * 50
+    lam, inv_bg = 0.7, 1.0 / 24
+    R_g, R_s, coef, us = ops.pg_rewards(dist.to(dev), tl.to(dev), lam, inv_bg)
+    Lf = np.maximum(tl.numpy(), 1).astype(np.float64)
+    rg = -dist[:B].numpy() / Lf; rs = -dist[B:].numpy() / Lf
+    np.testing.assert_allclose(R_g.cpu().numpy(), rg, rtol=1e-6)
+    np.testing.assert_allclose(R_s.cpu().numpy(), rs, rtol=1e-6)
+    np.testing.assert_allclose(coef.cpu().numpy(), lam * inv_bg * (rs - rg), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(us.cpu().numpy(), inv_bg / Lf, rtol=1e-6)
+    terms = ops.pg_loss_value(lp.to(dev), path.to(dev), il.to(dev), nll.to(dev), us, coef)
+    lpn = lp.double().numpy()
+    want = np.zeros(B)
+    for b in range(B):
+        s = sum(lpn[t, b, int(path[t, b])] for t in range(int(il[b])))
+        want[b] = float(nll[b]) * (inv_bg / Lf[b]) - lam * inv_bg * (rs[b] - rg[b]) * s
+    np.testing.assert_allclose(terms.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+    again = ops.pg_loss_value(lp.to(dev), path.to(dev), il.to(dev), nll.to(dev), us, coef)
+    assert torch.equal(terms, again)                                   # fixed-order reduction
+
+
 @pytest.mark.parametrize("T,B,V", [(1, 1, 2), (17, 3, 29), (1000, 32, 29), (33, 5, 64)])
 def test_argmax_bit_exact_and_sampler(ops, dev, T, B, V):
     g = torch.Generator().manual_seed(T + V)
