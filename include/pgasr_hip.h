@@ -203,7 +203,9 @@ int pgasr_log_softmax_rows(const float* logits, long long rows, int V, float* lo
  *   the activations (i,f,g,o) on exit; out (T,B,2H) = h; cbuf (T,B,2,H) = c.
  * pgasr_lstm_layer_bwd: dout (T,B,2H) -> gates overwritten in place by d(pre-activation gates);
  *   the caller forms dX = dgates * wih_perm, dW_ih = dgates^T X, dW_hh = dgates^T h_prev with
- *   pgasr_gemm_f32 and maps them back with pgasr_lstm_unpack_grads.
+ *   pgasr_gemm_f32 and maps them back with pgasr_lstm_unpack_grads.  dbias_part (optional, 16-byte aligned,
+ *   ceil(B/16) x 2*4H floats): per 16-utterance group, the sum over t of dgates in gates' column order -- the bias
+ *   gradient is the sum of its rows (saves a 262 MB column-sum pass over dgates at B=32,T=1000).
  * The sweeps are persistent kernels: 16 workgroups per (direction, 16-utterance group) that hand
  * h_t / partial dh sums to each other through global memory every step (self-validating words; plain
  * stores when the cluster is verified to share an XCD, write-through stores otherwise).
@@ -232,7 +234,7 @@ int pgasr_lstm_layer_fwd(float* gates, float* out, float* cbuf, const void* whh_
                          void* workspace, size_t workspace_bytes, void* stream);
 int pgasr_lstm_layer_bwd(float* gates, const float* out, const float* cbuf, const float* dout,
                          const void* whh_pack_bwd, const int32_t* lengths, int T, int B, int flags,
-                         void* workspace, size_t workspace_bytes, void* stream);
+                         float* dbias_part, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A7  CTC prefix beam search (CTCdecoder.py:41-116), one workgroup per utterance.
@@ -257,11 +259,13 @@ int pgasr_ctc_beam_search(const void* log_probs, int is_f64, long long stride_t,
  *   inter-layer dropout model.py:42 p=0.3).  keep is a pure function of (seed, offset, element
  *   index) (Philox4x32-10 on counter (index/4, offset), word index%4 >= p*2^32), so the backward
  *   pass re-applies the SAME call to the gradient instead of storing a mask.  x == y allowed.
+ *   dact_y (optional, n elements): the result is also multiplied by (dact_y > 0 ? 1 : slope) -- the backward
+ *   of F.leaky_relu (model.py:50) fused into the backward of the dropout that follows it (model.py:51).
  * pgasr_adam_step: torch.optim.Adam update (model.py:207, lr=5e-4) on flat fp32 buffers;
  *   step is the 1-based step count used for bias correction.
  * ---------------------------------------------------------------------------------------- */
 int pgasr_dropout(const float* x, float* y, unsigned long long n, float p, uint64_t seed, uint32_t offset,
-                  void* stream);
+                  const float* dact_y, float slope, void* stream);
 int pgasr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, unsigned long long n,
                     int step, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 

@@ -41,7 +41,7 @@ SIGNATURES = {
     "pgasr_beam_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "pgasr_ctc_beam_search": (C.c_int, [c_ptr, C.c_int, C.c_longlong, C.c_longlong, c_i32p, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, c_i32p, c_i32p, c_ptr, c_ptr, C.c_size_t, c_ptr]),
-    "pgasr_dropout": (C.c_int, [c_f32p, c_f32p, C.c_ulonglong, C.c_float, C.c_uint64, C.c_uint32, c_ptr]),
+    "pgasr_dropout": (C.c_int, [c_f32p, c_f32p, C.c_ulonglong, C.c_float, C.c_uint64, C.c_uint32, c_f32p, C.c_float, c_ptr]),
     "pgasr_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_ulonglong, C.c_int, C.c_float, C.c_float,
                                   C.c_float, C.c_float, C.c_float, c_ptr]),
     "pgasr_gemm_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
@@ -68,7 +68,7 @@ SIGNATURES = {
     "pgasr_lstm_layer_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int,
                                        c_ptr, C.c_size_t, c_ptr]),
     "pgasr_lstm_layer_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int,
-                                       c_ptr, C.c_size_t, c_ptr]),
+                                       c_f32p, c_ptr, C.c_size_t, c_ptr]),
 }
 
 

@@ -54,6 +54,7 @@ struct LstmArgs {
     float* out;              // [T][B][2H]   h_t (zeros past each length)
     float* cbuf;             // [T][B][2][H] c_t
     const float* dout;       // [T][B][2H]   (backward) gradient w.r.t. out
+    float* dbias_part;       // (backward, optional) [ceil(B/16)][2][H][4]: per 16-utterance group sums over t of dgates
     const u32x4* wpack;      // packed bf16 hi/lo W_hh in MFMA A-operand order (see pack kernel)
     unsigned char* xbuf;     // exchange buffers, pre-filled with the "stale" pattern
     unsigned* hello;         // [clusters][16] start-up words (XCC id of each member), zeroed per call
@@ -514,6 +515,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     const int bidx = bg * 16 + pn;
     const int len = (bidx < B) ? a.lengths[bidx] : 0;
     float dc = 0.f, carry = 0.f;
+    float4 dbs = make_float4(0, 0, 0, 0);      // running sum over the sweep of this cell's dgates (bias gradient)
 
     // ---- loader / storer: lane L serves cells 64k+L for the 16-byte gate rows and cells 4L..4L+3 for 4-byte rows
     auto step_t = [&](int s) { return dir ? s : T - 1 - s; };
@@ -598,6 +600,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
                 d.w = dh * tc * go * (1.f - go);
                 if (active) { dc = dct * gf; carry = 0.f; }
                 else { d = make_float4(0, 0, 0, 0); carry = dh_rec; }
+                dbs.x += d.x; dbs.y += d.y; dbs.z += d.z; dbs.w += d.w;
                 {
                     unsigned short hi[4], lo[4];
                     split_plain(d.x, hi[0], lo[0]); split_plain(d.y, hi[1], lo[1]);
@@ -647,6 +650,21 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
                     else          __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 16);
                 }
             }
+        }
+    }
+    if (a.dbias_part) {
+        // bias gradient for free: sum the per-cell running sums over the group's 16 utterances in a fixed order
+        __syncthreads();                 // the storer wave has read rdg for the last step
+        if (w < IO_WAVE) rdg[0][tid] = dbs;
+        __syncthreads();
+        if (tid < 16) {
+            float4 sum = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float4 v = rdg[0][u * 16 + tid];
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+            *reinterpret_cast<float4*>(a.dbias_part + (((size_t)bg * 2 + dir) * HID + 16 * g + tid) * 4) = sum;
         }
     }
 done:
@@ -747,6 +765,12 @@ __global__ __launch_bounds__(256) void lstm_unpack_kernel(UnpackArgs u) {
     }
 }
 
+__global__ __launch_bounds__(256) void lstm_prepare_kernel(u32x4* head, unsigned nhead, u32x4* xbuf, unsigned nx) {
+    const unsigned i0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    for (unsigned i = i0; i < nhead; i += stride) head[i] = (u32x4){0u, 0u, 0u, 0u};
+    for (unsigned i = i0; i < nx; i += stride) xbuf[i] = (u32x4){1u, 1u, 1u, 1u};
+}
+
 struct WsLayout { size_t err, hello, progress, xbuf, xbytes, stamps, total; int NBG, NCL8; };
 WsLayout lstm_ws_layout(int B, bool backward) {
     WsLayout l;
@@ -816,7 +840,7 @@ extern "C" size_t pgasr_lstm_workspace_bytes(int T, int B, int backward) {
     return lstm_ws_layout(B, backward != 0).total;
 }
 
-static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, const float* dout, const void* wpack,
+static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, const float* dout, float* dbias_part, const void* wpack,
                        const int* lengths, int T, int B, int flags, void* workspace, size_t workspace_bytes, hipStream_t st) {
     if (!gates || !out || !cbuf || !wpack || !lengths || T <= 0 || B <= 0) return PGASR_ERR_INVALID_ARG;
     if (backward && !dout) return PGASR_ERR_INVALID_ARG;
@@ -825,11 +849,13 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
     // every cluster must be co-resident, one workgroup per CU: at most 2 clusters per XCD
     if (2 * l.NBG > 16) return PGASR_ERR_UNSUPPORTED;
     char* ws = (char*)workspace;
-    if (hipMemsetAsync(ws + l.err, 0, l.xbuf - l.err, st) != hipSuccess) return PGASR_ERR_LAUNCH;
-    // every exchange word starts as "stale for epoch 0": bit0 = 1
-    if (hipMemsetD32Async((hipDeviceptr_t)(ws + l.xbuf), 0x00000001, l.xbytes / 4, st) != hipSuccess) return PGASR_ERR_LAUNCH;
+    // one launch: zero the head block (error flag, busy counters, hello and progress words) and set every exchange
+    // word to "stale for epoch 0" (bit0 = 1)
+    PGASR_LAUNCH_KERNEL(lstm_prepare_kernel, dim3(64), dim3(256), 0, st, (u32x4*)(ws + l.err), (unsigned)((l.xbuf - l.err) / 16),
+                       (u32x4*)(ws + l.xbuf), (unsigned)(l.xbytes / 16));
+    PGASR_CHECK_LAUNCH();
     LstmArgs a;
-    a.gates = gates; a.out = out; a.cbuf = cbuf; a.dout = dout; a.wpack = (const u32x4*)wpack;
+    a.gates = gates; a.out = out; a.cbuf = cbuf; a.dout = dout; a.dbias_part = dbias_part; a.wpack = (const u32x4*)wpack;
     a.xbuf = (unsigned char*)(ws + l.xbuf); a.hello = (unsigned*)(ws + l.hello); a.err = (int*)(ws + l.err);
     a.busy = (unsigned*)(ws + l.err + 64);   // 8 words inside the zeroed 256-byte head block
     a.progress = (unsigned*)(ws + l.progress);
@@ -850,14 +876,15 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
 extern "C" int pgasr_lstm_layer_fwd(float* gates, float* out, float* cbuf, const void* whh_pack_fwd,
                                     const int32_t* lengths, int T, int B, int flags,
                                     void* workspace, size_t workspace_bytes, void* stream) {
-    return lstm_launch(false, gates, out, cbuf, nullptr, whh_pack_fwd, lengths, T, B, flags, workspace, workspace_bytes,
+    return lstm_launch(false, gates, out, cbuf, nullptr, nullptr, whh_pack_fwd, lengths, T, B, flags, workspace, workspace_bytes,
                        (hipStream_t)stream);
 }
 
 extern "C" int pgasr_lstm_layer_bwd(float* gates, const float* out, const float* cbuf, const float* dout,
                                     const void* whh_pack_bwd, const int32_t* lengths, int T, int B, int flags,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
-    return lstm_launch(true, gates, const_cast<float*>(out), const_cast<float*>(cbuf), dout, whh_pack_bwd, lengths, T, B,
+                                    float* dbias_part, void* workspace, size_t workspace_bytes, void* stream) {
+    if (dbias_part && (((size_t)dbias_part) & 15)) return PGASR_ERR_INVALID_ARG;
+    return lstm_launch(true, gates, const_cast<float*>(out), const_cast<float*>(cbuf), dout, dbias_part, whh_pack_bwd, lengths, T, B,
                        flags, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

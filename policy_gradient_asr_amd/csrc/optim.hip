@@ -18,7 +18,8 @@ __device__ __forceinline__ void keep4(unsigned long long quad, uint32_t offset, 
 
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                       unsigned long long n, uint32_t thresh, float scale,
-                                                      uint32_t k0, uint32_t k1, uint32_t offset) {
+                                                      uint32_t k0, uint32_t k1, uint32_t offset,
+                                                      const float* __restrict__ dact_y, float slope) {
     const unsigned long long nq = (n + 3) / 4;
     for (unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x; q < nq;
          q += (unsigned long long)gridDim.x * 256) {
@@ -26,13 +27,19 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
         keep4(q, offset, k0, k1, thresh, keep);
         const unsigned long long i = q * 4;
         if (i + 4 <= n) {
-            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            float4 v = *reinterpret_cast<const float4*>(x + i);
+            if (dact_y) {       // backward through leaky_relu as well: times leaky'(pre) = (y > 0 ? 1 : slope)
+                const float4 a = *reinterpret_cast<const float4*>(dact_y + i);
+                v.x *= a.x > 0.f ? 1.f : slope; v.y *= a.y > 0.f ? 1.f : slope;
+                v.z *= a.z > 0.f ? 1.f : slope; v.w *= a.w > 0.f ? 1.f : slope;
+            }
             float4 o;
             o.x = keep[0] ? v.x * scale : 0.f; o.y = keep[1] ? v.y * scale : 0.f;
             o.z = keep[2] ? v.z * scale : 0.f; o.w = keep[3] ? v.w * scale : 0.f;
             *reinterpret_cast<float4*>(y + i) = o;
         } else {
-            for (int k = 0; k < 4 && i + k < n; ++k) y[i + k] = keep[k] ? x[i + k] * scale : 0.f;
+            for (int k = 0; k < 4 && i + k < n; ++k)
+                y[i + k] = keep[k] ? x[i + k] * scale * (dact_y ? (dact_y[i + k] > 0.f ? 1.f : slope) : 1.f) : 0.f;
         }
     }
 }
@@ -76,15 +83,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }  // namespace
 
 extern "C" int pgasr_dropout(const float* x, float* y, unsigned long long n, float p, uint64_t seed, uint32_t offset,
-                             void* stream) {
+                             const float* dact_y, float slope, void* stream) {
     if (!x || !y || n == 0 || !(p >= 0.f) || !(p < 1.f)) return PGASR_ERR_INVALID_ARG;
-    if ((((size_t)x) | ((size_t)y)) & 15) return PGASR_ERR_INVALID_ARG;
+    if ((((size_t)x) | ((size_t)y) | ((size_t)dact_y)) & 15) return PGASR_ERR_INVALID_ARG;
     const uint32_t thresh = (uint32_t)fmin(4294967295.0, (double)p * 4294967296.0);
     const unsigned long long nq = (n + 3) / 4;
     unsigned blocks = (unsigned)((nq + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     PGASR_LAUNCH_KERNEL(dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, n, thresh,
-                       1.f / (1.f - p), (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), offset);
+                       1.f / (1.f - p), (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), offset, dact_y, slope);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }

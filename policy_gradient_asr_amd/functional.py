@@ -114,14 +114,22 @@ class DropoutFn(torch.autograd.Function):
     the same kernel call to the gradient (no stored mask)."""
 
     @staticmethod
-    def forward(ctx, x, p, seed, offset):
+    def forward(ctx, x, p, seed, offset, *opt):
+        """fuse_leaky_backward: x is the OUTPUT of a leaky_relu whose producer leaves the leaky' factor to its
+        consumer (InstNormAffineFn(consumer_applies_dact=True)); backward then applies mask and leaky'(x) in one pass."""
         ctx.cfg = (float(p), int(seed), int(offset))
-        return hipops.dropout(x.contiguous(), p, seed, offset)
+        x = x.contiguous()
+        ctx.fused = bool(opt[0]) if opt else False          # opt = (fuse_leaky_backward,)
+        ctx.nopt = len(opt)
+        if ctx.fused:
+            ctx.save_for_backward(x)
+        return hipops.dropout(x, p, seed, offset)
 
     @staticmethod
     def backward(ctx, dy):
         p, seed, offset = ctx.cfg
-        return hipops.dropout(dy.contiguous(), p, seed, offset), None, None, None
+        dact = ctx.saved_tensors[0] if ctx.fused else None
+        return (hipops.dropout(dy.contiguous(), p, seed, offset, dact_y=dact, slope=LEAKY_SLOPE), None, None, None) + (None,) * ctx.nopt
 
 
 class LinearFn(torch.autograd.Function):
@@ -138,6 +146,7 @@ class LinearFn(torch.autograd.Function):
         hipops.gemm(x2, weight, y, M=rows, N=N, K=K, transB=True, bias=bias.contiguous())
         ctx.save_for_backward(x2, weight)
         ctx.shp = shp
+        ctx.param_refs = (weight, bias)
         return y.view(*shp[:-1], N)
 
     @staticmethod
@@ -148,6 +157,19 @@ class LinearFn(torch.autograd.Function):
         dy2 = dy.contiguous().view(rows, N)
         dx = torch.empty(rows, K, dtype=torch.float32, device=dy.device)
         hipops.gemm(dy2, weight, dx, M=rows, N=K, K=N)
+        wg, bg = (p.grad for p in ctx.param_refs)
+        if grad_overlap.enabled and wg is not None and bg is not None and wg.is_contiguous() and bg.is_contiguous():
+            # only dx is on the chain: the weight gradient joins the side-stream work that runs beside the next sweep
+            done = torch.cuda.Event()
+            done.record()
+
+            def weight_grads():
+                hipops.gemm(dy2, x2, wg, M=N, N=K, K=rows, transA=True, lda=N, splitk=_pick_splitk(N, K, rows), accumulate=True)
+                hipops.colsum(dy2, rows, N, N, bg, accumulate=True)
+            grad_overlap._pending.append((done, weight_grads))
+            side = grad_overlap.side_stream()
+            dy2.record_stream(side); x2.record_stream(side)
+            return dx.view(ctx.shp), None, None
         dW = torch.empty(N, K, dtype=torch.float32, device=dy.device)
         hipops.gemm(dy2, x2, dW, M=N, N=K, K=rows, transA=True, lda=N, splitk=_pick_splitk(N, K, rows))
         db = torch.empty(N, dtype=torch.float32, device=dy.device)
@@ -173,15 +195,19 @@ class BLSTMLayerFn(torch.autograd.Function):
     per-utterance lengths (packed-sequence semantics of model.py:52-55)."""
 
     @staticmethod
-    def forward(ctx, x, lengths, dact_y, sweep_follows, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+    def forward(ctx, x, lengths, dact_y, sweep_follows, prepacked, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
         T, B, I = x.shape
         x = x.contiguous()
-        params = [p.contiguous() for p in (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)]
-        wih_perm, bias_perm, pack_f, pack_b = hipops.lstm_pack(params, I)
+        if prepacked is None:
+            prepacked = prepack_blstm((w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r), I)
+        elif prepacked.ready is not None:
+            torch.cuda.current_stream().wait_event(prepacked.ready)
+        wih_perm, bias_perm, pack_f, pack_b = prepacked.wih_perm, prepacked.bias_perm, prepacked.pack_f, prepacked.pack_b
+        ctx.planes_t = prepacked.planes_t
         G = 2 * 4 * HID
         gates = torch.empty(T, B, G, dtype=torch.float32, device=x.device)
-        if hipops.gemm_x3w_ok(T * B, G, I):      # LDS-DMA kernel, weight pre-split into bf16 hi/lo planes
-            hipops.gemm_x3w(x, hipops.split_planes(wih_perm), gates, T * B, G, I, bias=bias_perm)
+        if prepacked.planes is not None and hipops.gemm_x3w_ok(T * B, G, I):   # LDS-DMA kernel, pre-split weight planes
+            hipops.gemm_x3w(x, prepacked.planes, gates, T * B, G, I, bias=bias_perm)
         else:
             hipops.gemm(x, wih_perm, gates, M=T * B, N=G, K=I, transB=True, bias=bias_perm)
         out = torch.empty(T, B, 2 * HID, dtype=torch.float32, device=x.device)
@@ -203,7 +229,7 @@ class BLSTMLayerFn(torch.autograd.Function):
         if grad_overlap.enabled:
             before = torch.cuda.Event()
             before.record()
-        hipops.lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B)   # gates := dgates
+        _, dbias_part = hipops.lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=True)   # gates := dgates
         dg = gates
         if grad_overlap.enabled:
             # the layer above left its weight-gradient GEMMs for now: they run beside THIS sweep, whose clusters
@@ -214,8 +240,8 @@ class BLSTMLayerFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, B, I, dtype=torch.float32, device=dev)
-            if hipops.gemm_x3w_ok(T * B, I, G):
-                hipops.gemm_x3w(dg, hipops.split_planes(wih_perm, transpose=True), dx, T * B, I, G,
+            if ctx.planes_t is not None and hipops.gemm_x3w_ok(T * B, I, G):
+                hipops.gemm_x3w(dg, ctx.planes_t, dx, T * B, I, G,
                                 dact_y=dact_y if ctx.has_dact else None, slope=LEAKY_SLOPE)
             else:
                 hipops.gemm(dg, wih_perm, dx, M=T * B, N=I, K=G, dact_y=dact_y if ctx.has_dact else None,
@@ -224,7 +250,7 @@ class BLSTMLayerFn(torch.autograd.Function):
             dwih = torch.empty(G, I, dtype=torch.float32, device=dev)
             hipops.gemm(dg, x, dwih, M=G, N=I, K=T * B, transA=True, lda=G, splitk=_pick_splitk(G, I, T * B))
             dbias = torch.empty(G, dtype=torch.float32, device=dev)
-            hipops.colsum(dg, T * B, G, G, dbias)
+            hipops.colsum(dbias_part, dbias_part.shape[0], G, G, dbias)      # the sweep summed dgates over t per group
             dwhh = torch.zeros(2, 4 * HID, HID, dtype=torch.float32, device=dev)
             if T > 1:
                 # dW_hh[d] = sum_t dgates_t[d]^T h_{prev(t)}[d];  prev = t-1 (fwd) / t+1 (rev); one launch, 2 batches
@@ -248,14 +274,50 @@ class BLSTMLayerFn(torch.autograd.Function):
             grad_overlap._pending.append((swept, lambda: weight_grads(accumulate_into=targets)))
             if not ctx.sweep_follows:
                 grad_overlap.flush()       # nothing left to hide behind: go now
-            for t_ in (dg, x, out):
+            for t_ in (dg, x, out, dbias_part):
                 t_.record_stream(side)
-            return (dx, None, None, None) + (None,) * 8
+            return (dx, None, None, None, None) + (None,) * 8
         gl = weight_grads()
-        return (dx, None, None, None, *gl)
+        return (dx, None, None, None, None, *gl)
 
 
-def blstm_layer(x, lengths, params, dact_y=None, sweep_follows=False):
+class PackedBLSTM:
+    """What a sweep needs of one layer's parameters, in kernel layouts (made once per step)."""
+    __slots__ = ("wih_perm", "bias_perm", "pack_f", "pack_b", "planes", "planes_t", "ready")
+
+
+def prepack_blstm(params, in_dim):
+    pk = PackedBLSTM()
+    params = [p.contiguous() for p in params]
+    pk.wih_perm, pk.bias_perm, pk.pack_f, pk.pack_b = hipops.lstm_pack(params, in_dim)
+    G = 2 * 4 * HID
+    ok = in_dim % 32 == 0 and in_dim % 128 == 0          # both GEMM roles of W_ih: N=G,K=in and N=in,K=G
+    pk.planes = hipops.split_planes(pk.wih_perm) if ok else None                      # (G, in): forward projection
+    pk.planes_t = hipops.split_planes(pk.wih_perm, transpose=True) if ok else None    # (in, G): input gradient
+    pk.ready = None
+    return pk
+
+
+def prepack_blstm_layers(layer_params, in_dims):
+    """All layers' packs on the side stream (they depend on the parameters only); each carries the event the
+    consuming stream waits for."""
+    main = torch.cuda.current_stream()
+    side = grad_overlap.side_stream()
+    side.wait_stream(main)          # the parameters may still be being written (previous step's Adam)
+    out = []
+    with torch.cuda.stream(side):
+        for params, in_dim in zip(layer_params, in_dims):
+            pk = prepack_blstm(params, in_dim)
+            pk.ready = torch.cuda.Event()
+            pk.ready.record()
+            for t in (pk.wih_perm, pk.bias_perm, pk.pack_f, pk.pack_b) + (pk.planes or ()) + (pk.planes_t or ()):
+                t.record_stream(main)
+            out.append(pk)
+    return out
+
+
+def blstm_layer(x, lengths, params, dact_y=None, sweep_follows=False, prepacked=None):
     """sweep_follows: in the backward pass the sweep of the layer BELOW runs right after this layer's
-    (True for every layer but the first) -- lets the overlapped weight-gradient GEMMs stay off its XCDs."""
-    return BLSTMLayerFn.apply(x, lengths, dact_y, sweep_follows, *params)
+    (True for every layer but the first) -- lets the overlapped weight-gradient GEMMs stay off its XCDs.
+    prepacked: a PackedBLSTM made from ``params`` (else packed here)."""
+    return BLSTMLayerFn.apply(x, lengths, dact_y, sweep_follows, prepacked, *params)

@@ -367,14 +367,17 @@ def lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B):
     return ws
 
 
-def lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B):
+def lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=False):
+    """gates := d(pre-activation gates).  want_dbias: also returns the (ceil(B/16), 2*4H) per-group bias-gradient
+    partial sums the sweep accumulates on the way (sum its rows)."""
     lib = _lib.load()
     ws = _lstm_ws(T, B, True, gates.device)
+    part = torch.empty((B + 15) // 16, 2 * 4 * HID, dtype=torch.float32, device=gates.device) if want_dbias else None
     with _timed("lstm_bwd_kernel"):
         st = lib.pgasr_lstm_layer_bwd(_p(gates), _p(out), _p(cbuf), _p(dout), _p(pack_b), _p(lengths), T, B, LSTM_FLAGS,
-                                      _p(ws), ws.numel(), _stream())
+                                      _p(part), _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_lstm_layer_bwd")
-    return ws
+    return (ws, part) if want_dbias else ws
 
 
 def lstm_check_error(ws, B, backward):
@@ -416,13 +419,16 @@ def ctc_beam_search(log_probs, lengths=None, beam=5, blank=0):
 # ------------------------------------------------------------------------------------------
 # dropout / Adam
 # ------------------------------------------------------------------------------------------
-def dropout(x, p, seed, offset, out=None):
+def dropout(x, p, seed, offset, out=None, dact_y=None, slope=0.01):
+    """Inverted dropout; with ``dact_y`` the result is also multiplied by leaky'(dact_y) (fused backward)."""
     lib = _lib.load()
-    _req(x, torch.float32, "x")
+    _req(x, torch.float32, "x"); _req(dact_y, torch.float32, "dact_y")
+    if dact_y is not None and dact_y.numel() != x.numel():
+        raise _lib.PgasrError("dropout: dact_y must have x's size")
     if out is None:
         out = torch.empty_like(x)
     _lib.check(lib.pgasr_dropout(_p(x), _p(out), x.numel(), float(p), int(seed) & (2 ** 64 - 1),
-                                 int(offset) & 0xFFFFFFFF, _stream()), "pgasr_dropout")
+                                 int(offset) & 0xFFFFFFFF, _p(dact_y), float(slope), _stream()), "pgasr_dropout")
     return out
 
 

@@ -62,6 +62,7 @@ class PGCTCLossFn(torch.autograd.Function):
         loss = hipops.pg_loss_value(lp, sample, in_len, nll, utt_scale, coef).sum()
         ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(nll, R_s, R_g)
+        ctx.set_materialize_grads(False)        # no zero-filled gradients for the three statistics
         return loss, nll, R_s, R_g
 
     @staticmethod

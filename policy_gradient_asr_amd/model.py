@@ -63,14 +63,18 @@ class Encoder(nn.Module):
             raise RuntimeError("policy_gradient_asr_amd.Encoder runs on the MI355X only (no CPU fallback)")
         lengths = mask.sum(dim=1).to(torch.int32).contiguous()   # stays on the device: no host sync
         training = self.training
-        fuse = not training
-        y = Fh.InstNormAffineFn.apply(x.float(), self.input_layer.weight, self.input_layer.bias, fuse)
+        # weight repacking (gate-permuted W_ih, its bf16 planes, the register-resident W_hh packs) depends on the
+        # parameters only: all three layers' packs are made on a side stream while the front end runs
+        packs = Fh.prepack_blstm_layers([self._layer_params(l) for l in range(3)], [512, 512, 512])
+        # the affine's leaky'(y) factor is applied by whoever consumes y in the backward pass: the dropout that
+        # follows it (train) or the first layer's input-gradient GEMM epilogue (eval)
+        y = Fh.InstNormAffineFn.apply(x.float(), self.input_layer.weight, self.input_layer.bias, True)
         h = y
         if training:                                   # nn.Dropout(), model.py:45,51
-            h = Fh.DropoutFn.apply(h, self.drop.p, self.dropout_seed, self._next_drop_offset())
+            h = Fh.DropoutFn.apply(h, self.drop.p, self.dropout_seed, self._next_drop_offset(), True)
         for l in range(3):
-            h = Fh.blstm_layer(h, lengths, self._layer_params(l), dact_y=y if (l == 0 and fuse) else None,
-                               sweep_follows=(l > 0))
+            h = Fh.blstm_layer(h, lengths, self._layer_params(l), dact_y=y if (l == 0 and not training) else None,
+                               sweep_follows=(l > 0), prepacked=packs[l])
             if training and l < 2:                     # nn.LSTM(dropout=0.3), model.py:42: outputs of layers 0,1
                 h = Fh.DropoutFn.apply(h, self.blstm.dropout, self.dropout_seed, self._next_drop_offset())
         return h, lengths
