@@ -158,6 +158,14 @@ def test_dropout_kernel_mask_and_backward():
     out.backward(torch.ones_like(out))
     assert torch.equal(xg.grad != 0, out != 0) and torch.allclose(xg.grad[out != 0], torch.tensor(2.0, device=DEV))
     assert torch.equal(hipops.dropout(x, 0.0, 1, 1), x)
+    # leaky_relu -> dropout, the leaky' factor applied by the dropout's backward (model.py:50-51 in train mode)
+    pre = torch.randn(333, 37, device=DEV)            # odd size: scalar tail path as well
+    yv = torch.nn.functional.leaky_relu(pre, 0.01).requires_grad_(True)
+    out = Fh.DropoutFn.apply(yv, 0.5, 11, 3, True)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    want = hipops.dropout(gout, 0.5, 11, 3) * torch.where(pre > 0, 1.0, 0.01)
+    torch.testing.assert_close(yv.grad, want, rtol=1e-6, atol=0)
 
 
 def test_adam_kernel_matches_torch():
