@@ -33,9 +33,15 @@ _prof_on = False
 _prof_events = []
 
 
-def profile_reset(enable):
-    global _prof_on
+_prof_only = None
+
+
+def profile_reset(enable, only=None):
+    """only: iterable of name prefixes to time (None = every instrumented launch); an event pair costs a few
+    microseconds of stream time, so bench.py times just the kernels its roofline is about inside the timed region."""
+    global _prof_on, _prof_only
     _prof_on = bool(enable)
+    _prof_only = tuple(only) if only else None
     _prof_events.clear()
 
 
@@ -54,13 +60,14 @@ class _timed:
         self.name = name
 
     def __enter__(self):
-        if _prof_on:
+        self.on = _prof_on and (_prof_only is None or self.name.startswith(_prof_only))
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True); self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
         return self
 
     def __exit__(self, *a):
-        if _prof_on:
+        if self.on:
             self.e1.record()
             _prof_events.append((self.name, self.e0, self.e1))
         return False
