@@ -18,8 +18,10 @@ for k in sorted(acc):
     c = {n: sum(v.values()) / len(v) for n, v in acc[k].items()}
     for n in sorted(c):
         lines.append(f"    {n:28s} {c[n]:16.0f}")
-    if "SQ_BUSY_CYCLES" in c and c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
-        lines.append(f"    -> MFMA pipe busy / SQ busy            {c['SQ_VALU_MFMA_BUSY_CYCLES'] / c['SQ_BUSY_CYCLES']:.3f}")
+    if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs; MFMA busy cycles are summed over the 1024 SIMDs
+        lines.append(f"    -> MFMA pipe busy (per SIMD, of kernel cycles)  {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}")
+        lines.append(f"    -> VALU issue (4 cycles/inst, per SIMD)         {4 * c.get('SQ_INSTS_VALU', 0) / (c['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}")
     if c.get("SQ_WAVE_CYCLES"):
         lines.append(f"    -> wave cycles waiting (SQ_WAIT_ANY)   {c.get('SQ_WAIT_ANY', 0) / c['SQ_WAVE_CYCLES']:.3f}")
         lines.append(f"    -> wave cycles issuing (ACTIVE_INST)   {c.get('SQ_ACTIVE_INST_ANY', 0) / c['SQ_WAVE_CYCLES']:.3f}")
