@@ -23,14 +23,23 @@ class grad_overlap:
     stream wait for the side stream; call it after loss.backward()."""
     enabled = False
     confine = True     # keep side-stream GEMMs off the XCDs of the concurrent LSTM sweep
-    _side = None
-    _pending = []      # (ready event, closure) of the layer above, issued right AFTER the next sweep is launched
+    _sides = {}        # one side stream and one pending list PER main stream (micro-batches run on their own streams)
+    _pendings = {}     # (ready event, closure) of the layer above, issued right AFTER the next sweep is launched
+
+    @classmethod
+    def _key(cls):
+        return torch.cuda.current_stream().cuda_stream
 
     @classmethod
     def side_stream(cls):
-        if cls._side is None:
-            cls._side = torch.cuda.Stream()
-        return cls._side
+        k = cls._key()
+        if k not in cls._sides:
+            cls._sides[k] = torch.cuda.Stream()
+        return cls._sides[k]
+
+    @classmethod
+    def pending(cls):
+        return cls._pendings.setdefault(cls._key(), [])
 
     @classmethod
     def flush(cls, busy_ptr=0, launched_after=None):
@@ -38,31 +47,32 @@ class grad_overlap:
         has been launched: a kernel with a large grid enqueued BEFORE the sweep holds up the dispatch of
         everything behind it, on any stream (rocprof: the sweep's 5 us memset waited 616 us for the GEMM
         in front of it), so the order of enqueueing is sweep first, GEMMs second."""
-        if not cls._pending:
+        pending = cls.pending()
+        if not pending:
             return
         side = cls.side_stream()
         prev = hipops.GEMM_XCC_BUSY_PTR
         hipops.GEMM_XCC_BUSY_PTR = busy_ptr if cls.confine else 0
         try:
             with torch.cuda.stream(side):
-                for ready, fn in cls._pending:
+                for ready, fn in pending:
                     side.wait_event(ready)
                 if launched_after is not None and busy_ptr:
                     # enqueue order says nothing about dispatch order when the host runs ahead: wait for the point
                     # on the main stream just before the sweep, then for the sweep's clusters to register
                     side.wait_event(launched_after)
                     hipops.stream_gate(busy_ptr)
-                for ready, fn in cls._pending:
+                for ready, fn in pending:
                     fn()
         finally:
             hipops.GEMM_XCC_BUSY_PTR = prev
-            cls._pending = []
+            del pending[:]
 
     @classmethod
     def finish(cls):
         cls.flush()
-        if cls._side is not None:
-            torch.cuda.current_stream().wait_stream(cls._side)
+        if cls._key() in cls._sides:
+            torch.cuda.current_stream().wait_stream(cls.side_stream())
 
 
 class InstNormAffineFn(torch.autograd.Function):
@@ -166,7 +176,7 @@ class LinearFn(torch.autograd.Function):
             def weight_grads():
                 hipops.gemm(dy2, x2, wg, M=N, N=K, K=rows, transA=True, lda=N, splitk=_pick_splitk(N, K, rows), accumulate=True)
                 hipops.colsum(dy2, rows, N, N, bg, accumulate=True)
-            grad_overlap._pending.append((done, weight_grads))
+            grad_overlap.pending().append((done, weight_grads))
             side = grad_overlap.side_stream()
             dy2.record_stream(side); x2.record_stream(side)
             return dx.view(ctx.shp), None, None
@@ -271,7 +281,7 @@ class BLSTMLayerFn(torch.autograd.Function):
         targets = [p.grad for p in ctx.param_refs]
         if grad_overlap.enabled and all(t is not None and t.is_contiguous() for t in targets):
             side = grad_overlap.side_stream()
-            grad_overlap._pending.append((swept, lambda: weight_grads(accumulate_into=targets)))
+            grad_overlap.pending().append((swept, lambda: weight_grads(accumulate_into=targets)))
             if not ctx.sweep_follows:
                 grad_overlap.flush()       # nothing left to hide behind: go now
             for t_ in (dg, x, out, dbias_part):

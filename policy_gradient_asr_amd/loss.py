@@ -35,7 +35,7 @@ class PGCTCLossFn(torch.autograd.Function):
     for the sampled (R_s) and greedy (R_g, baseline) paths; Bg = global batch (all ranks).
     Returns (loss, stats) where stats = (nll (B), R_s (B), R_g (B)) detached."""
 
-    _lattice_stream = None
+    _lattice_streams = {}      # one lattice stream per calling stream
 
     @staticmethod
     def forward(ctx, logits, in_len, targets, tg_len, lam, seed, offset, global_batch, blank):
@@ -46,8 +46,8 @@ class PGCTCLossFn(torch.autograd.Function):
         # on a side stream beside sampling, collapse, edit distance and the reward arithmetic, which the gradient pass
         # then joins.
         main = torch.cuda.current_stream()
-        side = PGCTCLossFn._lattice_stream or torch.cuda.Stream()
-        PGCTCLossFn._lattice_stream = side
+        side = PGCTCLossFn._lattice_streams.setdefault(main.cuda_stream, None) or torch.cuda.Stream()
+        PGCTCLossFn._lattice_streams[main.cuda_stream] = side
         side.wait_stream(main)
         with torch.cuda.stream(side):
             nll, lattice = hipops.ctc_lattice(lp, targets, in_len, tg_len, blank=blank)
