@@ -269,6 +269,25 @@ int pgasr_dropout(const float* x, float* y, unsigned long long n, float p, uint6
 int pgasr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, unsigned long long n,
                     int step, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * N3  feature front end (data.py:44-79): MFCC(40) + delta + delta-delta of torchaudio's defaults
+ *   (16 kHz, n_fft 400, hop 200, periodic Hann, reflect-centred frames, power spectrum, 128 HTK mel bands,
+ *   10*log10 floored at the utterance's max - top_db, orthonormal DCT-II; 5-tap delta filter with replicate
+ *   padding).  The DFT / mel / DCT contractions are pgasr_gemm_f32 calls made by the host between these:
+ *   pgasr_feat_frames:  wave (B rows of wave_stride samples), n_samples (B), n_frames (B) = 1 + n_samples/200
+ *                       -> frames (B*Tmax, 400), windowed, zero rows past an utterance's frames
+ *   pgasr_feat_power:   spec (rows, 402) = [re(201) | im(201)] -> power (rows, 201)
+ *   pgasr_feat_db:      in place on mel (B, Tmax, n_mels)
+ *   pgasr_feat_deltas_stack: mfcc (B, Tmax, n_mfcc) -> feat (B, 3*n_mfcc, Tmax) zero padded (the reference's
+ *                       batch layout, data.py:71-79), fmask (B, 1, Tmax) (optional)
+ * ---------------------------------------------------------------------------------------- */
+int pgasr_feat_frames(const float* wave, const int32_t* n_samples, const int32_t* n_frames, int B,
+                      long long wave_stride, int Tmax, float* frames, void* stream);
+int pgasr_feat_power(const float* spec, long long rows, float* power, void* stream);
+int pgasr_feat_db(float* mel, const int32_t* n_frames, int B, int Tmax, int n_mels, float top_db, void* stream);
+int pgasr_feat_deltas_stack(const float* mfcc, const int32_t* n_frames, int B, int Tmax, int n_mfcc,
+                            float* feat, float* fmask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

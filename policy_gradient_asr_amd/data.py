@@ -2,9 +2,9 @@
 
 ``collate_custom`` returns the reference's batch dict {"feat" (B,F,Tmax) fp32 zero padded,
 "fmask" (B,1,Tmax), "trans" (B,Lmax) int64 pad 0, "tmask" (B,Lmax)} (data.py:107-116).  Feature
-extraction (``extract_feats``, data.py:44-79: MFCC(40)+delta+delta-delta via torchaudio) is out of
-scope of the hot path; it is kept as a torchaudio-gated function so the driver shells run
-wherever torchaudio exists, and ``SyntheticSpeech`` supplies ready-made features otherwise."""
+extraction (``extract_feats``, data.py:44-79: MFCC(40)+delta+delta-delta, torchaudio's defaults) runs on the GPU
+(features.py); torchaudio is only used to decode audio files where it exists (RIFF WAV is read
+without it), and ``SyntheticSpeech`` supplies ready-made features for the benchmarks."""
 import os
 
 import torch
@@ -23,23 +23,35 @@ def pad_feats(feats):
     return torch.stack(padded), torch.stack(masks)
 
 
-def extract_feats(batch):
-    """MFCC + deltas as data.py:44-62 (needs torchaudio) or precomputed "feat" entries."""
-    feats = []
+_front_end = {}
+
+
+def extract_feats(batch, device="cuda:0"):
+    """data.py:44-79: MFCC(40) + delta + delta-delta per utterance, zero padded to (B,120,Tmax) + (B,1,Tmax) masks.
+    An item carries precomputed features ("feat", (F,T)), a waveform tensor ("wave"), or a path ("aud", read with
+    torchaudio where it exists, else as RIFF WAV).  Waveforms go through the GPU front end (features.MFCCDeltas);
+    the result is returned on the CPU like the reference's collate output."""
+    if all("feat" in inst for inst in batch):
+        return pad_feats([inst["feat"] for inst in batch])
+    if any("feat" in inst for inst in batch):
+        raise ValueError("a batch mixes precomputed features and waveforms")
+    from .features import MFCCDeltas, read_wav
+    waves = []
     for inst in batch:
-        if "feat" in inst:
-            feats.append(inst["feat"])
+        if "wave" in inst:
+            waves.append(inst["wave"])
             continue
         try:
             import torchaudio
-        except ImportError as e:  # pragma: no cover - torchaudio absent in this image
-            raise ImportError("feature extraction (data.py:44-62) needs torchaudio; pass precomputed 'feat'") from e
-        waveform, _sr = torchaudio.load(inst["aud"])
-        mfcc = torchaudio.transforms.MFCC()(waveform)
-        d1 = torchaudio.transforms.ComputeDeltas()(mfcc)
-        d2 = torchaudio.transforms.ComputeDeltas()(d1)
-        feats.append(torch.cat((mfcc, d1, d2), dim=1).squeeze(0))
-    return pad_feats(feats)
+            waveform, _sr = torchaudio.load(inst["aud"])          # data.py:53
+            waves.append(waveform[0])
+        except ImportError:
+            waves.append(read_wav(inst["aud"])[0])
+    fe = _front_end.get(device)
+    if fe is None:
+        fe = _front_end[device] = MFCCDeltas(device)
+    feat, fmask = fe(waves)
+    return feat.cpu(), fmask.cpu()
 
 
 def encode_trans(batch):

@@ -180,3 +180,29 @@ def test_sampler_and_reinforce_grad():
     obj = -(picked * mask * torch.tensor(coef)[None, :]).sum()
     obj.backward()
     np.testing.assert_allclose(g, lt.grad.numpy(), rtol=1e-9, atol=1e-12)
+
+
+def test_feature_oracle_stages_are_pinned():
+    """oracle/features_ref.py restates torchaudio (absent here): pin the stages that have an independent
+    implementation in this image -- STFT against torch.stft, DCT against scipy, deltas against a convolution."""
+    import scipy.fft
+    from oracle import features_ref as fr
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal(5000) * 0.1
+    p = fr.power_spectrogram(w)
+    st = torch.stft(torch.from_numpy(w), n_fft=400, hop_length=200, win_length=400,
+                    window=torch.hann_window(400, dtype=torch.float64), center=True, pad_mode="reflect",
+                    normalized=False, onesided=True, return_complex=True)
+    np.testing.assert_allclose(p, (st.abs() ** 2).T.numpy(), rtol=1e-10, atol=1e-14)
+    x = rng.standard_normal((7, 128))
+    np.testing.assert_allclose(x @ fr.dct_matrix(40, 128), scipy.fft.dct(x, type=2, norm="ortho", axis=1)[:, :40], atol=1e-12)
+    y = rng.standard_normal((3, 11))
+    pad = np.pad(y, ((0, 0), (2, 2)), mode="edge")
+    want = sum(m * pad[:, 2 + m:2 + m + 11] for m in range(-2, 3)) / 10.0
+    np.testing.assert_allclose(fr.compute_deltas(y), want, atol=1e-12)
+    fb = fr.mel_filterbank()
+    assert fb.shape == (201, 128) and (fb >= 0).all() and fb.max() <= 1.0
+    f = fr.mfcc_deltas(w)
+    assert f.shape == (120, 26)
+    feats, mask = fr.extract_feats([w, w[:3000]])
+    assert feats.shape == (2, 120, 26) and mask[1, 0].sum() == 16 and np.all(feats[1, :, 16:] == 0)
