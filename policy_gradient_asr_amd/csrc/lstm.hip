@@ -238,7 +238,7 @@ __device__ __forceinline__ void prefetcher_loop(const LstmArgs& a, int cl, int d
 // (xproj / saved activations) a few steps ahead straight into an LDS ring with LDS-DMA
 // (global_load_lds: no register result) behind a hand-counted s_waitcnt vmcnt(N).  Wave 5 is the
 // STORER: it copies the cells' results (staged in LDS) to HBM and never waits on memory.
-// Reason (measured, tools_lstm_diag.py): vmcnt retires in order and hipcc emits only vmcnt(0) in
+// Reason (measured, tools/dev/tools_lstm_diag.py): vmcnt retires in order and hipcc emits only vmcnt(0) in
 // this kernel, so any DRAM-latency load or scattered store issued by a compute wave sits in
 // front of its polling loads -- the sweep ran 1.63 ms with that traffic in the compute waves and
 // 1.05 ms without it, while a cached load in the same place cost nothing.

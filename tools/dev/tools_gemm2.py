@@ -1,6 +1,6 @@
 """Ad-hoc timing of the LDS-DMA GEMM (development aid)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from policy_gradient_asr_amd import hipops
 dev = torch.device("cuda:0")

@@ -1,6 +1,6 @@
 """Host-side enqueue time per train step vs GPU time (development aid)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from policy_gradient_asr_amd.model import Seq2Seq, weights
 from policy_gradient_asr_amd.train_step import PolicyGradientTrainer

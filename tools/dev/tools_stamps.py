@@ -1,6 +1,6 @@
 """Diagnostic: per-phase cycle breakdown of one LSTM forward sweep (needs `make stamps`)."""
 import os, sys
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PGASR_HIP_LIB"] = os.path.join(ROOT, "policy_gradient_asr_amd", "libpgasr_hip_stamps.so")
 sys.path.insert(0, ROOT)
 import torch

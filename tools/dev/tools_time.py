@@ -1,6 +1,6 @@
 """Ad-hoc timing of the path's pieces on the GPU (development aid, not part of the product)."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from policy_gradient_asr_amd import hipops
 from policy_gradient_asr_amd.model import Seq2Seq, weights

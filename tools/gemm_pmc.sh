@@ -13,6 +13,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   rm -rf "$O/${TAG}_gemm_pmc$i"
-  timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d "$O/${TAG}_gemm_pmc$i" -- python3 "$R/tools_gemm2.py" > "$O/${TAG}_gemm_pmc$i.log" 2>&1 || { echo "pass $i failed"; exit 1; }
+  timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d "$O/${TAG}_gemm_pmc$i" -- python3 "$R/tools/dev/tools_gemm2.py" > "$O/${TAG}_gemm_pmc$i.log" 2>&1 || { echo "pass $i failed"; exit 1; }
 done
 echo "gemm_pmc done"

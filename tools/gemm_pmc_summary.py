@@ -12,7 +12,7 @@ for f in sorted(glob.glob(os.path.join(root, "gpurun_out", f"{tag}_gemm_pmc*", "
             continue
         k = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         acc[k][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
-lines = [f"# mean per launch; source: tools/gemm_pmc.sh {tag} on tools_gemm2.py (M=32000: NT K=512 N=2048, NN K=2048 N=512)"]
+lines = [f"# mean per launch; source: tools/gemm_pmc.sh {tag} on tools/dev/tools_gemm2.py (M=32000: NT K=512 N=2048, NN K=2048 N=512)"]
 for k in sorted(acc):
     lines.append(k)
     c = {n: sum(v.values()) / len(v) for n, v in acc[k].items()}
