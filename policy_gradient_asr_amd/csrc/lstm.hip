@@ -169,7 +169,10 @@ __device__ __forceinline__ bool cluster_same_xcd(const LstmArgs& a, int cl, int 
 // touches the lines the cluster will need PREFETCH_AHEAD steps from now (one 4-byte load per
 // 128-byte line), so that the compute waves' own loads hit in the XCD's L2.  It carries no data
 // and no correctness: if it lands on another XCD or falls behind, the sweep is merely slower.
-constexpr int PREFETCH_AHEAD = 6;
+#ifndef PGASR_PREFETCH_AHEAD
+#define PGASR_PREFETCH_AHEAD 6
+#endif
+constexpr int PREFETCH_AHEAD = PGASR_PREFETCH_AHEAD;
 
 __device__ __forceinline__ void prefetcher_loop(const LstmArgs& a, int cl, int dir, int bg, bool backward) {
     const int tid = threadIdx.x;
@@ -245,7 +248,13 @@ __device__ __forceinline__ void prefetcher_loop(const LstmArgs& a, int cl, int d
 // ------------------------------------------------------------------------------------------
 constexpr int IO_WAVE = 4;        // first non-compute wave
 constexpr int LOADER_WAVE = 4, STORER_WAVE = 5;
-constexpr int FWD_LEAD = 3, FWD_RING = 5;   // loader runs 3 steps ahead; ring slot reuse distance 5 > lead + 1
+#ifndef PGASR_FWD_LEAD
+#define PGASR_FWD_LEAD 3
+#endif
+#ifndef PGASR_PREFETCH_AHEAD
+#define PGASR_PREFETCH_AHEAD 6
+#endif
+constexpr int FWD_LEAD = PGASR_FWD_LEAD, FWD_RING = FWD_LEAD + 2;   // loader runs FWD_LEAD steps ahead; ring slot reuse distance > lead + 1
 constexpr int BWD_LEAD = 4, BWD_RING = 6;
 
 // one LDS-DMA wave-instruction: 64 lanes x 16 B, per-lane global source, LDS destination = base + lane*16
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
             const int t = step_t(step);
             if (w == LOADER_WAVE) {
                 loader_issue(step + FWD_LEAD);
-                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // = 4*FWD_LEAD: this step's rows have landed
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * FWD_LEAD) : "memory");   // this step's rows have landed
             }
             if (g == 0 && tid == 0) {   // paces the prefetcher; a plain store (shared L2) unless the cluster spans XCDs
                 if (same_xcd) *reinterpret_cast<volatile unsigned*>(a.progress + cl * 32) = (unsigned)step;
@@ -389,7 +398,6 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
                 for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    if ((a.diag & 256) && i == 1) break;      // diagnostic: half the MFMA work (results invalid)
 #pragma unroll
                     for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[m][i], Hhi[i], acc[m], 0, 0, 0);
 #pragma unroll
@@ -422,14 +430,13 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
                     pre.z += (p0.z + p1.z) + (p2.z + p3.z);
                     pre.w += (p0.w + p1.w) + (p2.w + p3.w);
                 }
-                const bool cheap = (a.diag & 512) != 0;       // diagnostic: no transcendentals (results invalid)
-                const float gi = cheap ? pre.x * 0.5f : sigmoidf_fast(pre.x);
-                const float gf = cheap ? pre.y * 0.5f : sigmoidf_fast(pre.y);
-                const float gg = cheap ? pre.z * 0.5f : tanhf_fast(pre.z);
-                const float go = cheap ? pre.w * 0.5f : sigmoidf_fast(pre.w);
+                const float gi = sigmoidf_fast(pre.x);
+                const float gf = sigmoidf_fast(pre.y);
+                const float gg = tanhf_fast(pre.z);
+                const float go = sigmoidf_fast(pre.w);
                 const bool active = t < len;
                 const float cn = gf * c + gi * gg;
-                const float hn = go * (cheap ? cn * 0.5f : tanhf_fast(cn));
+                const float hn = go * tanhf_fast(cn);
                 if (active) { c = cn; h = hn; }
                 if (step + 1 < T) {
                     // publish h_t: each cell thread writes its own bf16 hi and lo (2-byte stores);
