@@ -52,10 +52,14 @@ __device__ __forceinline__ double lse3(double a0, double a1, double a2) {
     const double m = fmax(fmax(a0, a1), a2);
     if (m == -INFINITY) return -INFINITY;
     const float s = __expf((float)(a0 - m)) + __expf((float)(a1 - m)) + __expf((float)(a2 - m));
-    return m + (double)__logf(s);
+    // s is in [1, 3]: the bare v_log_f32 (log2) needs none of __logf's denormal / range fix-ups, which sat on the chain
+    return m + (double)(0.6931471805599453f * __builtin_amdgcn_logf(s));
 }
 
-__global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(
+// NSPT = states per thread, a compile-time constant: the common case S <= 256 (L <= 127) runs with no per-state
+// loop or bound checks on the T-step chain (measured 492 -> see DESIGN.md at T=1000, S=201).
+template <int NSPT>
+__global__ __launch_bounds__(CTC_THREADS + 64) void ctc_lattice_kernel(
     const float* __restrict__ lp, const int32_t* __restrict__ targets,
     const int32_t* __restrict__ in_len, const int32_t* __restrict__ tg_len,
     int T, int B, int V, int Lmax, int Smax, int blank, CtcWs ws, float* __restrict__ nll_out, int role_base) {
@@ -96,15 +100,21 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(
     }
 
     // row buffers: position p = s + 2, two guard cells of -inf on each side
-    __shared__ double row[2][CTC_SMAX + 4];
-    for (int i = tid; i < 2 * (CTC_SMAX + 4); i += CTC_THREADS) (&row[0][0])[i] = -INFINITY;
+    constexpr int ROW = NSPT * CTC_THREADS + 4;
+    __shared__ double row[2][ROW];
+    // Wave 4 is the STORER: it copies each finished row from LDS to the alpha/beta array.  With the store in the
+    // compute threads the chain waited every step for the store's write acknowledgement: hipcc must use vmcnt(0)
+    // for the emission prefetch as soon as a store is also outstanding (loads and stores retire out of order
+    // with respect to each other) -- 391 us against 492 us before the NSPT template, see DESIGN.md.
+    const bool storer = tid >= CTC_THREADS;
+    for (int i = tid; i < 2 * ROW; i += CTC_THREADS + 64) (&row[0][0])[i] = -INFINITY;
 
     // per-thread state descriptors
-    int lab[CTC_SPT];
-    bool skip[CTC_SPT];   // alpha: may come from s-2 ; beta: may go to s+2
+    int lab[NSPT];
+    bool skip[NSPT];   // alpha: may come from s-2 ; beta: may go to s+2
 #pragma unroll
-    for (int j = 0; j < CTC_SPT; ++j) {
-        const int s = tid + j * CTC_THREADS;
+    for (int j = 0; j < NSPT; ++j) {
+        const int s = storer ? S : tid + j * CTC_THREADS;       // the storer owns no state
         lab[j] = blank; skip[j] = false;
         if (s < S && (s & 1)) lab[j] = tgt[s >> 1];
         if (role == 0) {
@@ -126,7 +136,6 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(
         return;
     }
 
-    const int nspt = (S + CTC_THREADS - 1) / CTC_THREADS;  // live strided slots
     const int t0 = (role == 0) ? 0 : Tb - 1;
     const int dt = (role == 0) ? 1 : -1;
 
@@ -134,9 +143,8 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(
     {
         const float* lpt = lp + ((size_t)t0 * B + b) * V;
 #pragma unroll
-        for (int j = 0; j < CTC_SPT; ++j) {
-            if (j >= nspt) break;
-            const int s = tid + j * CTC_THREADS;
+        for (int j = 0; j < NSPT; ++j) {
+            const int s = storer ? S : tid + j * CTC_THREADS;
             if (s < S) {
                 double v = -INFINITY;
                 if (role == 0) { if (s <= 1) v = (double)lpt[lab[j]]; }
@@ -147,40 +155,63 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(
         }
     }
     int cur = 0;
-    float lpn[CTC_SPT];
-    if (Tb > 1) {
-        const float* lpt = lp + ((size_t)(t0 + dt) * B + b) * V;
-#pragma unroll
-        for (int j = 0; j < CTC_SPT; ++j) lpn[j] = (j < nspt) ? lpt[lab[j]] : 0.f;
-    }
-    for (int k = 1; k < Tb; ++k) {
-        const int t = t0 + k * dt;
-        float lpc[CTC_SPT];
-#pragma unroll
-        for (int j = 0; j < CTC_SPT; ++j) lpc[j] = lpn[j];
-        if (k + 1 < Tb) {  // prefetch the next frame's emissions: off the dependent chain
-            const float* lpt = lp + ((size_t)(t + dt) * B + b) * V;
-#pragma unroll
-            for (int j = 0; j < CTC_SPT; ++j) lpn[j] = (j < nspt) ? lpt[lab[j]] : 0.f;
-        }
-        __syncthreads();
-        const double* rc = row[cur];
-        double* rn = row[cur ^ 1];
-#pragma unroll
-        for (int j = 0; j < CTC_SPT; ++j) {
-            if (j >= nspt) break;
-            const int s = tid + j * CTC_THREADS;
-            if (s < S) {
-                const int p = s + 2;
-                double a0 = rc[p], a1, a2;
-                if (role == 0) { a1 = rc[p - 1]; a2 = skip[j] ? rc[p - 2] : -INFINITY; }
-                else           { a1 = rc[p + 1]; a2 = skip[j] ? rc[p + 2] : -INFINITY; }
-                const double v = lse3(a0, a1, a2) + (double)lpc[j];
-                rn[p] = v;
-                out[(size_t)t * Smax + s] = v;
+    // LDS-only barrier: __syncthreads() would also drain vmcnt (the storer's stores, the emission prefetch)
+#define ROW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); \
+                           asm volatile("" ::: "memory"); } while (0)
+    if (storer) {
+        // its own loop (same number of barriers): nothing in this path ever waits for a store
+        for (int k = 1; k < Tb; ++k) {
+            ROW_BARRIER();
+            if (k >= 2) {    // row[cur] = frame t0 + (k-1)*dt, stable until the next barrier; frame t0 was stored by its writers
+                const double* rc = row[cur];
+                double* o = out + (size_t)(t0 + (k - 1) * dt) * Smax;
+                for (int s = tid - CTC_THREADS; s < S; s += 64) o[s] = rc[s + 2];
             }
+            cur ^= 1;
         }
-        cur ^= 1;
+    } else {
+        float lpn[NSPT];
+#pragma unroll
+        for (int j = 0; j < NSPT; ++j) lpn[j] = 0.f;
+        if (Tb > 1) {
+            const float* lpt = lp + ((size_t)(t0 + dt) * B + b) * V;
+#pragma unroll
+            for (int j = 0; j < NSPT; ++j) lpn[j] = lpt[lab[j]];
+        }
+        for (int k = 1; k < Tb; ++k) {
+            const int t = t0 + k * dt;
+            float lpc[NSPT];
+#pragma unroll
+            for (int j = 0; j < NSPT; ++j) lpc[j] = lpn[j];
+            if (k + 1 < Tb) {  // prefetch the next frame's emissions: off the dependent chain
+                const float* lpt = lp + ((size_t)(t + dt) * B + b) * V;
+#pragma unroll
+                for (int j = 0; j < NSPT; ++j) lpn[j] = lpt[lab[j]];
+            }
+            ROW_BARRIER();
+            const double* rc = row[cur];
+            double* rn = row[cur ^ 1];
+#pragma unroll
+            for (int j = 0; j < NSPT; ++j) {
+                const int s = tid + j * CTC_THREADS;
+                if (s < S) {
+                    const int p = s + 2;
+                    double a0 = rc[p], a1, a2;
+                    if (role == 0) { a1 = rc[p - 1]; a2 = skip[j] ? rc[p - 2] : -INFINITY; }
+                    else           { a1 = rc[p + 1]; a2 = skip[j] ? rc[p + 2] : -INFINITY; }
+                    rn[p] = lse3(a0, a1, a2) + (double)lpc[j];
+                }
+            }
+            cur ^= 1;
+        }
+    }
+#undef ROW_BARRIER
+    if (Tb > 1) {        // the last frame's row
+        __syncthreads();
+        if (storer) {
+            double* o = out + (size_t)(t0 + (Tb - 1) * dt) * Smax;
+            for (int s = tid - CTC_THREADS; s < S; s += 64) o[s] = row[cur][s + 2];
+        }
     }
     if (role == 0) {
         __syncthreads();
@@ -269,9 +300,13 @@ extern "C" int pgasr_ctc_loss_grad(const float* log_probs, const int32_t* target
     // Lmax == 0 still needs a valid targets row pointer; Lmax>=1 is the caller's job.
     // (a single-wave register-resident variant was measured SLOWER: 850 us vs 492 us at S=201 --
     // one wave's fp64 VALU issue rate, not the barrier, is then the limit)
-    PGASR_LAUNCH_KERNEL(ctc_lattice_kernel, dim3(B, 3), dim3(CTC_THREADS), 0, st,
-                        log_probs, targets, input_lengths, target_lengths, T, B, V,
-                        Lmax > 0 ? Lmax : 1, Smax, blank, ws, nll, 0);
+#define PGASR_LATTICE(NSPT) PGASR_LAUNCH_KERNEL(ctc_lattice_kernel<NSPT>, dim3(B, 3), dim3(CTC_THREADS + 64), 0, st, \
+                        log_probs, targets, input_lengths, target_lengths, T, B, V, Lmax > 0 ? Lmax : 1, Smax, blank, ws, nll, 0)
+    if (Smax <= CTC_THREADS) PGASR_LATTICE(1);
+    else if (Smax <= 2 * CTC_THREADS) PGASR_LATTICE(2);
+    else if (Smax <= 4 * CTC_THREADS) PGASR_LATTICE(4);
+    else PGASR_LATTICE(8);
+#undef PGASR_LATTICE
     PGASR_CHECK_LAUNCH();
     if (grad_logits) {
         const long long waves = (long long)T * B;
