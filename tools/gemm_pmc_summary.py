@@ -5,7 +5,13 @@ from collections import defaultdict
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 acc = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))     # kernel -> counter -> dispatch -> sum
-for f in sorted(glob.glob(os.path.join(root, "gpurun_out", f"{tag}_gemm_pmc*", "**", "*counter_collection.csv"), recursive=True)):
+# gpurun merges runs into the same directories: keep the newest counter file of each pass
+newest = {}
+for f in glob.glob(os.path.join(root, "gpurun_out", f"{tag}_gemm_pmc*", "**", "*counter_collection.csv"), recursive=True):
+    d = f.split(os.sep + "gpurun_out" + os.sep)[1].split(os.sep)[0]
+    if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+        newest[d] = f
+for f in sorted(newest.values()):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "gemm" not in k:

@@ -17,7 +17,7 @@ def one(pattern):
     hits = glob.glob(os.path.join(out, pattern), recursive=True)
     if not hits:
         raise SystemExit(f"missing {pattern}")
-    return hits[0]
+    return max(hits, key=os.path.getmtime)      # gpurun merges runs into the same directory: take the newest
 
 
 def short(name):
