@@ -115,3 +115,53 @@ class SyntheticSpeech(data.Dataset):
 
     def __getitem__(self, idx):
         return self.items[idx]
+
+
+class LengthBucketSampler(data.Sampler):
+    """Batch sampler for variable-length utterances (replaces ``shuffle=True`` of model.py:221):
+    utterances are sorted by length, cut into buckets of ``bucket_batches`` batches, shuffled inside each bucket and
+    the resulting batches are shuffled -- every batch holds utterances of similar length, so little of the
+    (B, F, Tmax) tensor is padding and the persistent LSTM sweeps (whose time is Tmax steps whatever the lengths)
+    do little idle work.  Deterministic per (seed, epoch); ``set_epoch`` like a DistributedSampler."""
+
+    def __init__(self, lengths, batch_size, bucket_batches=16, seed=0, drop_last=False):
+        self.lengths = [int(n) for n in lengths]
+        self.batch_size, self.bucket_batches, self.seed, self.drop_last = int(batch_size), int(bucket_batches), int(seed), drop_last
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        n = len(self.lengths)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed * 100003 + self.epoch)
+        order = sorted(range(len(self.lengths)), key=lambda i: self.lengths[i])
+        span = self.batch_size * self.bucket_batches
+        batches = []
+        for s in range(0, len(order), span):
+            bucket = order[s:s + span]
+            perm = torch.randperm(len(bucket), generator=g).tolist()
+            bucket = [bucket[i] for i in perm]
+            for b in range(0, len(bucket), self.batch_size):
+                batch = bucket[b:b + self.batch_size]
+                if len(batch) == self.batch_size or not self.drop_last:
+                    batches.append(batch)
+        for i in torch.randperm(len(batches), generator=g).tolist():
+            yield batches[i]
+
+
+def dataset_lengths(dataset):
+    """Frame counts of a dataset whose items carry precomputed features or waveforms (None if unknown, e.g. paths)."""
+    out = []
+    for i in range(len(dataset)):
+        item = dataset[i]
+        if "feat" in item:
+            out.append(int(item["feat"].shape[1]))
+        elif "wave" in item:
+            out.append(1 + int(item["wave"].numel()) // 200)
+        else:
+            return None
+    return out

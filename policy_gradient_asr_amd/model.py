@@ -147,7 +147,7 @@ def _to_device(batch, device):
 
 
 def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset=None, dev_dataset=None,
-          n_feats=120, lam=1.0, lr=5e-4, resume=True, log_every=10, seed=0):
+          n_feats=120, lam=1.0, lr=5e-4, resume=True, log_every=10, seed=0, bucket_by_length=True):
     """Epoch loop of model.py:186-274 on the MI355X path: per-epoch train loss -> train_loss.npy,
     validation CTC loss -> val_losses.npy, model_best.pth / model_last.pth (state_dicts, reference
     names), plus checkpoint_last.pth (model + Adam moments + epoch) from which ``resume`` restarts
@@ -156,7 +156,7 @@ def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset
     import os
     import numpy as np
     import torch.utils.data as tud
-    from .data import Data, collate_custom
+    from .data import Data, LengthBucketSampler, collate_custom, dataset_lengths
     from .loss import pg_ctc_loss
     from .train_step import PolicyGradientTrainer
 
@@ -186,7 +186,13 @@ def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset
     print("Start training...")
     for epoch in range(start_epoch, num_epochs + 1):
         model.train()
-        loader = tud.DataLoader(train_dataset, batch_size=batch_size, shuffle=True, collate_fn=collate_custom)
+        lens = dataset_lengths(train_dataset) if bucket_by_length else None
+        if lens is not None:      # similar lengths per batch instead of model.py:221's shuffle=True
+            sampler = LengthBucketSampler(lens, batch_size, seed=seed)
+            sampler.set_epoch(epoch)
+            loader = tud.DataLoader(train_dataset, batch_sampler=sampler, collate_fn=collate_custom)
+        else:
+            loader = tud.DataLoader(train_dataset, batch_size=batch_size, shuffle=True, collate_fn=collate_custom)
         acc = torch.zeros((), device=dev)
         for step, batch in enumerate(loader, 1):
             loss = trainer.step(*_to_device(batch, dev))

@@ -206,3 +206,19 @@ def test_feature_oracle_stages_are_pinned():
     assert f.shape == (120, 26)
     feats, mask = fr.extract_feats([w, w[:3000]])
     assert feats.shape == (2, 120, 26) and mask[1, 0].sum() == 16 and np.all(feats[1, :, 16:] == 0)
+
+
+def test_length_bucket_sampler():
+    from policy_gradient_asr_amd.data import LengthBucketSampler
+    g = torch.Generator().manual_seed(0)
+    lengths = torch.randint(50, 1000, (203,), generator=g).tolist()
+    s = LengthBucketSampler(lengths, batch_size=8, bucket_batches=4, seed=3)
+    batches = list(s)
+    assert len(batches) == len(s) == 26
+    assert sorted(i for b in batches for i in b) == list(range(203))          # every utterance exactly once
+    spread = max(max(lengths[i] for i in b) - min(lengths[i] for i in b) for b in batches if len(b) == 8)
+    assert spread < 0.35 * (max(lengths) - min(lengths))                       # similar lengths inside a batch
+    assert [b for b in s] == batches                                            # deterministic per epoch
+    s.set_epoch(1)
+    assert [b for b in s] != batches
+    assert len(list(LengthBucketSampler(lengths, 8, drop_last=True))) == 25
