@@ -10,6 +10,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The step uses three streams (main, weight-gradient side stream, CTC lattice) and RCCL adds its own: HIP's default of
+# 4 hardware queues makes streams share a queue and serialise behind each other.  Read by the runtime at start-up.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
