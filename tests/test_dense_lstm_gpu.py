@@ -222,3 +222,20 @@ def test_seq2seq_logprobs_and_grads_vs_oracle():
     for k, v in m.named_parameters():
         rk = k[len("encoder."):] if k.startswith("encoder.") else k
         assert rel_err(v.grad.cpu(), pr[rk].grad) < 2e-3, k
+
+
+def test_stream_gate_opens_on_busy_word_or_timeout():
+    """pgasr_stream_gate: a hint kernel -- returns at once when a busy word is set, after the time-out otherwise."""
+    import time
+    from policy_gradient_asr_amd import hipops
+    words = torch.zeros(8, dtype=torch.int32, device=DEV)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); hipops.stream_gate(words.data_ptr(), 8, timeout_us=20000); torch.cuda.synchronize()
+    waited = time.perf_counter() - t0
+    assert 0.015 < waited < 0.5                       # ~20 ms time-out, never a hang
+    words[5] = 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); hipops.stream_gate(words.data_ptr(), 8, timeout_us=20000); torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.01
+    with pytest.raises(Exception):
+        hipops.stream_gate(words.data_ptr(), 8, timeout_us=10 ** 7)       # beyond the documented 100 ms cap
