@@ -37,6 +37,16 @@ class grad_overlap:
             cls._sides[k] = torch.cuda.Stream()
         return cls._sides[k]
 
+    split_tail = True  # no sweep follows the first layer's backward: run its dW_hh beside its dW_ih
+    _sides2 = {}
+
+    @classmethod
+    def second_side_stream(cls):
+        k = cls._key()
+        if k not in cls._sides2:
+            cls._sides2[k] = torch.cuda.Stream()
+        return cls._sides2[k]
+
     @classmethod
     def pending(cls):
         return cls._pendings.setdefault(cls._key(), [])
@@ -256,18 +266,35 @@ class BLSTMLayerFn(torch.autograd.Function):
             else:
                 hipops.gemm(dg, wih_perm, dx, M=T * B, N=I, K=G, dact_y=dact_y if ctx.has_dact else None,
                             slope=LEAKY_SLOPE)
-        def weight_grads(accumulate_into=None):
+        def weight_grads(accumulate_into=None, hh_stream=None):
+            """hh_stream: run the dW_hh product on that stream, beside dW_ih (used where no sweep follows: the tail of
+            the step is then two GEMM chains wide instead of one long one)."""
+            cur = torch.cuda.current_stream()
+
+            def hh():
+                dwhh_ = torch.zeros(2, 4 * HID, HID, dtype=torch.float32, device=dev)
+                if T > 1:
+                    # dW_hh[d] = sum_t dgates_t[d]^T h_{prev(t)}[d];  prev = t-1 (fwd) / t+1 (rev); one launch, 2 batches
+                    K = (T - 1) * B
+                    hipops.gemm(dg, out, dwhh_, M=4 * HID, N=HID, K=K, transA=True, lda=G, ldb=2 * HID, ldc=HID,
+                                a_off=B * G, b_off=0, strideA=4 * HID - B * G, strideB=B * 2 * HID + HID,
+                                strideC=4 * HID * HID, batch=2, splitk=_pick_splitk(4 * HID, HID, K, 256))   # x2 batches; measured 8 -> 272 us, 16 -> 173 us
+                return dwhh_
+            if hh_stream is not None:
+                hh_stream.wait_stream(cur)
+                with torch.cuda.stream(hh_stream):
+                    dwhh = hh()
+                    for t_ in (dg, out):
+                        t_.record_stream(hh_stream)
+                dwhh.record_stream(cur)
             dwih = torch.empty(G, I, dtype=torch.float32, device=dev)
             hipops.gemm(dg, x, dwih, M=G, N=I, K=T * B, transA=True, lda=G, splitk=_pick_splitk(G, I, T * B))
             dbias = torch.empty(G, dtype=torch.float32, device=dev)
             hipops.colsum(dbias_part, dbias_part.shape[0], G, G, dbias)      # the sweep summed dgates over t per group
-            dwhh = torch.zeros(2, 4 * HID, HID, dtype=torch.float32, device=dev)
-            if T > 1:
-                # dW_hh[d] = sum_t dgates_t[d]^T h_{prev(t)}[d];  prev = t-1 (fwd) / t+1 (rev); one launch, 2 batches
-                K = (T - 1) * B
-                hipops.gemm(dg, out, dwhh, M=4 * HID, N=HID, K=K, transA=True, lda=G, ldb=2 * HID, ldc=HID,
-                            a_off=B * G, b_off=0, strideA=4 * HID - B * G, strideB=B * 2 * HID + HID,
-                            strideC=4 * HID * HID, batch=2, splitk=_pick_splitk(4 * HID, HID, K, 256))      # x2 batches; measured 8 -> 272 us, 16 -> 173 us
+            if hh_stream is not None:
+                cur.wait_stream(hh_stream)
+            else:
+                dwhh = hh()
             if accumulate_into is not None:
                 hipops.lstm_unpack_grads(dwih, dbias, dwhh, I, accumulate_into, accumulate=True)
                 return None
@@ -281,8 +308,10 @@ class BLSTMLayerFn(torch.autograd.Function):
         targets = [p.grad for p in ctx.param_refs]
         if grad_overlap.enabled and all(t is not None and t.is_contiguous() for t in targets):
             side = grad_overlap.side_stream()
-            grad_overlap.pending().append((swept, lambda: weight_grads(accumulate_into=targets)))
-            if not ctx.sweep_follows:
+            tail = not ctx.sweep_follows
+            hh_stream = grad_overlap.second_side_stream() if (tail and grad_overlap.split_tail) else None
+            grad_overlap.pending().append((swept, lambda: weight_grads(accumulate_into=targets, hh_stream=hh_stream)))
+            if tail:
                 grad_overlap.flush()       # nothing left to hide behind: go now
             for t_ in (dg, x, out, dbias_part):
                 t_.record_stream(side)
