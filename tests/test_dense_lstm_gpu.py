@@ -128,6 +128,9 @@ def _lstm_case(T, B, lens, seed, in_dim=512):
 @pytest.mark.parametrize("T,B,lens", [
     (5, 2, [5, 5]), (40, 4, [40, 33, 1, 17]), (64, 16, [64] * 16), (30, 19, list(range(30, 11, -1))),
     (200, 32, [200] * 32),
+    (1, 5, [1] * 5),                                # a single frame: no recurrent exchange at all
+    (3, 17, [3] * 9 + [1] * 8),                     # one utterance over a 16-utterance group: a second, nearly empty cluster pair
+    (7, 48, [7] * 20 + [4] * 28),                   # three groups = six clusters
 ])
 def test_blstm_layer_vs_torch_cpu(T, B, lens):
     from policy_gradient_asr_amd import functional as Fh
