@@ -23,7 +23,11 @@
 namespace {
 
 constexpr int HID = 256;           // hidden size per direction (model.py:40)
-constexpr int G_CLUSTER = 16;      // workgroups per (direction, batch group): 16 units each
+constexpr int G_CLUSTER = 16;      // compute workgroups per (direction, batch group): 16 units each
+constexpr int N_HELPERS = 4;       // + helper workgroups per cluster that stage the sweep's HBM rows into a hot ring
+constexpr int RING_STEPS = 16;     // depth of that ring (steps)
+constexpr int FWD_STEP_FLOATS = 16 * 1024;                           // 16 utterances x (256 units x 4 gates)
+constexpr int BWD_STEP_FLOATS = 16 * 1024 + 16 * 256 + 16 * 256;     // + c_t + dout
 constexpr int LSTM_THREADS = 384;     // 4 compute waves + loader wave + storer wave
 constexpr int STAMP_MAX_T = 4096;
 constexpr long long SPIN_TIMEOUT_TICKS = 300000000LL;  // 3 s of the 100 MHz realtime counter
@@ -58,7 +62,9 @@ struct LstmArgs {
     const u32x4* wpack;      // packed bf16 hi/lo W_hh in MFMA A-operand order (see pack kernel)
     unsigned char* xbuf;     // exchange buffers, pre-filled with the "stale" pattern
     unsigned* hello;         // [clusters][16] start-up words (XCC id of each member), zeroed per call
-    unsigned* progress;      // [clusters] current step of member 0 (paces the prefetcher), zeroed per call
+    unsigned* progress;      // [clusters] current step of member 0 (paces the helpers), zeroed per call
+    float* ring;             // [clusters][RING_STEPS][step floats]: the rows of the next steps, staged by the helper workgroups
+    unsigned* ready;         // [clusters][32]: words 0..15 = (step + 1) held by each ring slot (0 = nothing yet), zeroed per call
     int* err;                // set to 1 when a bounded wait gives up
     unsigned* busy;          // [8] per-XCD count of clusters currently sweeping there (read by queue-mode GEMMs)
     const int* lengths;      // [B]
@@ -162,77 +168,92 @@ __device__ __forceinline__ bool cluster_same_xcd(const LstmArgs& a, int cl, int 
 }
 
 
-// ---- the cluster's prefetcher workgroup (member index G_CLUSTER) ---------------------------
-// The compute waves must never wait on DRAM: vmcnt retires in order, so one HBM-latency load in
-// front of the polling loads delays the whole step (measured 0.4 us of a 1.6 us step).  The
-// prefetcher shares the cluster's XCD (same blockIdx % 8), follows member 0's progress word and
-// touches the lines the cluster will need PREFETCH_AHEAD steps from now (one 4-byte load per
-// 128-byte line), so that the compute waves' own loads hit in the XCD's L2.  It carries no data
-// and no correctness: if it lands on another XCD or falls behind, the sweep is merely slower.
-#ifndef PGASR_PREFETCH_AHEAD
-#define PGASR_PREFETCH_AHEAD 6
-#endif
-constexpr int PREFETCH_AHEAD = PGASR_PREFETCH_AHEAD;
-
-__device__ __forceinline__ void prefetcher_loop(const LstmArgs& a, int cl, int dir, int bg, bool backward) {
-    const int tid = threadIdx.x;
+// ---- the cluster's helper workgroups (member indices G_CLUSTER .. G_CLUSTER + N_HELPERS - 1) -------------
+// The compute workgroups must never touch DRAM: measured with the loader wave reading the real (HBM-cold) rows
+// the forward step took 1.51 us, reading L2-resident rows 1.30 us, reading nothing 1.26 us -- and an L2 "touch"
+// prefetcher running ahead on another CU did not change the first figure.  So the rows are MOVED: helper h copies
+// the rows of steps h, h + N_HELPERS, .. (16 utterances x 4 KiB of gates, plus c_t and dout for the backward
+// sweep) from HBM into a small ring that lives in the XCD's L2, and the compute workgroups' loader waves DMA
+// from the ring.  DRAM latency and traffic stay on the helpers' CUs.
+//   ready[slot] = step + 1 is published after the slot's stores are complete (vmcnt(0) in every wave, workgroup
+//   barrier, then one store); a slot is rewritten only once member 0 has passed the step it held by two
+//   (members are never more than one step apart), i.e. helpers run at most RING_STEPS - 2 steps ahead.
+//   Placement is verified, not assumed: a helper that finds itself on another XCD than member 0 writes the ring
+//   with write-through stores, and the loaders always read it with L1-bypassing loads.
+__device__ __forceinline__ void helper_loop(const LstmArgs& a, int cl, int dir, int bg, int h, bool backward,
+                                            volatile int* s_flag) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int T = a.T, B = a.B;
-    if (a.diag & 8) return;
-    // only useful on the cluster's own XCD: compare with member 0's start-up word, else leave
-    {
+    if (w >= 4) return;      // four waves move the rows (the barriers below count only live waves)
+    bool same = false;
+    {   // does the whole cluster sit on THIS XCD?  (the members' start-up words)
         const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xFu;
         SpinGuard sg0;
-        unsigned v;
+        unsigned v = 0x100u | xcc;
         while (true) {
             POLL_FENCE();
-            v = __hip_atomic_load(a.hello + (size_t)cl * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v != 0u) break;
+            if (lane < 16) v = __hip_atomic_load(a.hello + (size_t)cl * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!__any(v == 0u)) break;
             __builtin_amdgcn_s_sleep(8);
-            if (!sg0.keep_waiting()) return;
+            if (!sg0.keep_waiting()) { *a.err = 1; return; }
         }
-        if ((v & 0xFu) != xcc) return;
+        same = !__any((v & 0xFu) != xcc) && a.force_mode == 0;
     }
-    // Fire-and-forget: LDS-DMA loads have no register result, so nothing ever waits for them (the
-    // hardware just caps the number in flight); their LDS landing zone is scratch.  One wave-instruction
-    // moves 1 KiB (64 lanes x 16 B) = a quarter of one utterance's 4-KiB gate slice.
-    __shared__ __attribute__((aligned(16))) unsigned char scratch[4 * 1024];
-    const int lane = tid & 63, w = tid >> 6;
-    if (w >= 4) return;      // four waves are enough (no barriers in here)
+    const int step_floats = backward ? BWD_STEP_FLOATS : FWD_STEP_FLOATS;
+    float* ring = a.ring + (size_t)cl * RING_STEPS * step_floats;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ring, 0, (int)(RING_STEPS * step_floats * 4), 0x00020000);
+    unsigned* ready = a.ready + (size_t)cl * 32;
     SpinGuard sg;
-    for (int step = 0; step < T; ++step) {
-        while (true) {   // stay at most PREFETCH_AHEAD steps in front of the cluster; leave when it is done
+    for (int s = h; s < T; s += N_HELPERS) {
+        // back-pressure: slot s % RING_STEPS held step s - RING_STEPS
+        while (true) {
             POLL_FENCE();
             const unsigned cur = __hip_atomic_load(a.progress + cl * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cur + 1 >= (unsigned)T) return;
-            const unsigned ahead = (a.diag >> 5) ? (unsigned)(a.diag >> 5) : (unsigned)PREFETCH_AHEAD;   // diag bits 5-7 override
-            if ((unsigned)step <= cur + ahead) break;
-            __builtin_amdgcn_s_sleep(4);
-            if (!sg.keep_waiting()) return;
+            if ((unsigned)s <= cur + (unsigned)(RING_STEPS - 2)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (!sg.keep_waiting()) { *a.err = 1; return; }
         }
         sg.spins = 0;
-        const int t = backward ? (dir ? step : T - 1 - step) : (dir ? T - 1 - step : step);
-        if (a.diag & 16) continue;
+        const int t = backward ? (dir ? s : T - 1 - s) : (dir ? T - 1 - s : s);
+        const unsigned slot_off = (unsigned)((s % RING_STEPS) * step_floats);
+        u32x4 v[16];
+#pragma unroll
         for (int n = 0; n < 16; ++n) {
-            const int b = bg * 16 + n;
-            if (b >= B) break;
-            const float* row = a.gates + ((((size_t)t * B + b) * 2 + dir) * HID) * 4;
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(row + w * 256 + lane * 4),
-                                             (void __attribute__((address_space(3)))*)(scratch + w * 1024), 16, 0, 0);
+            int b = bg * 16 + n; b = b < B ? b : B - 1;
+            v[n] = *reinterpret_cast<const u32x4*>(a.gates + ((((size_t)t * B + b) * 2 + dir) * HID) * 4 + w * 256 + lane * 4);
         }
+        u32x4 vc[4], vd[4];
         if (backward) {
-            // c_t (also the next step's c_prev) and dout: 1 KiB per utterance each; wave w takes utterances w, w+4, ..
-            for (int k = 0; k < 4; ++k) {
-                const int b = bg * 16 + w + 4 * k;
-                if (b >= B) break;
-                const float* c = a.cbuf + (((size_t)t * B + b) * 2 + dir) * HID;
-                const float* d = a.dout + ((size_t)t * B + b) * (2 * HID) + dir * HID;
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(c + lane * 4),
-                                                 (void __attribute__((address_space(3)))*)(scratch + w * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(d + lane * 4),
-                                                 (void __attribute__((address_space(3)))*)(scratch + w * 1024), 16, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = j * 256 + tid;                  // 16-byte chunk of the 16 x 256 floats
+                int b = bg * 16 + (i >> 6); b = b < B ? b : B - 1;
+                vc[j] = *reinterpret_cast<const u32x4*>(a.cbuf + (((size_t)t * B + b) * 2 + dir) * HID + (i & 63) * 4);
+                vd[j] = *reinterpret_cast<const u32x4*>(a.dout + ((size_t)t * B + b) * (2 * HID) + dir * HID + (i & 63) * 4);
             }
         }
+        const int aux = same ? 0 : 16;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const unsigned off = (slot_off + (unsigned)(n * 1024 + w * 256 + lane * 4)) * 4u;
+            if (same) __builtin_amdgcn_raw_buffer_store_b128(v[n], rs, off, 0, 0);
+            else      __builtin_amdgcn_raw_buffer_store_b128(v[n], rs, off, 0, 16);
+        }
+        if (backward) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned i = (unsigned)(j * 256 + tid);
+                const unsigned oc = (slot_off + 16 * 1024 + i * 4) * 4u, od = (slot_off + 16 * 1024 + 16 * 256 + i * 4) * 4u;
+                if (same) { __builtin_amdgcn_raw_buffer_store_b128(vc[j], rs, oc, 0, 0); __builtin_amdgcn_raw_buffer_store_b128(vd[j], rs, od, 0, 0); }
+                else      { __builtin_amdgcn_raw_buffer_store_b128(vc[j], rs, oc, 0, 16); __builtin_amdgcn_raw_buffer_store_b128(vd[j], rs, od, 0, 16); }
+            }
+        }
+        (void)aux;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores are complete
+        __syncthreads();                                      // .. and so are the other three waves'
+        if (tid == 0) __hip_atomic_store(ready + (s % RING_STEPS), (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    (void)s_flag;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -251,12 +272,14 @@ constexpr int LOADER_WAVE = 4, STORER_WAVE = 5;
 #ifndef PGASR_FWD_LEAD
 #define PGASR_FWD_LEAD 3
 #endif
-#ifndef PGASR_PREFETCH_AHEAD
-#define PGASR_PREFETCH_AHEAD 6
-#endif
 constexpr int FWD_LEAD = PGASR_FWD_LEAD, FWD_RING = FWD_LEAD + 2;   // loader runs FWD_LEAD steps ahead; ring slot reuse distance > lead + 1
 constexpr int BWD_LEAD = 4, BWD_RING = 6;
 
+// the same with the agent-scope (L1-bypassing) policy: for data another workgroup has just written
+__device__ __forceinline__ void dma16_sc1(const void* gsrc, void* lds_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                     (void __attribute__((address_space(3)))*)lds_base, 16, 0, 16);
+}
 // one LDS-DMA wave-instruction: 64 lanes x 16 B, per-lane global source, LDS destination = base + lane*16
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_base) {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
@@ -264,7 +287,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_base) {
 }
 
 // ------------------------------------------------------------------------------------------
-// forward sweep.  1-D grid of 17*NCL8 workgroups (16 compute members + 1 prefetcher per cluster):
+// forward sweep.  1-D grid of (16 + N_HELPERS)*NCL8 workgroups (16 compute members + the helpers of each cluster):
 // cluster cl = b % NCL8 (members share b % 8, i.e. an XCD under the observed round-robin
 // placement), member g = b / NCL8 owns hidden units 16g..16g+15.  Wave w < 4 multiplies the
 // k-quarter [64w, 64w+64) of h_{t-1} into all 64 gate rows of the workgroup (4 MFMA tiles x 2
@@ -276,7 +299,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
     const int cl = blockIdx.x % a.NCL8, g = blockIdx.x / a.NCL8;
     if (cl >= 2 * a.NBG) return;
     const int dir = cl & 1, bg = cl >> 1;
-    if (g == G_CLUSTER) { prefetcher_loop(a, cl, dir, bg, false); return; }
+    if (g >= G_CLUSTER) { helper_loop(a, cl, dir, bg, g - G_CLUSTER, false, nullptr); return; }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = lane >> 4, n = lane & 15;      // MFMA coordinates
     const int pu = tid & 15, pn = (tid >> 4) & 15;   // cell coordinates of a compute thread (unit fastest)
@@ -323,14 +346,26 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
     };
     // 4 LDS-DMA instructions per step, ALWAYS issued (step and utterance clamped into range) so that the
     // counted wait below is exact: vmcnt(4*FWD_LEAD) leaves only the loads of the next FWD_LEAD steps in flight
+    const float* ring = a.ring + (size_t)cl * RING_STEPS * FWD_STEP_FLOATS;
+    const unsigned* ready = a.ready + (size_t)cl * 32;
+    auto ring_wait = [&](int s) {      // until the helpers have staged step s (wave-uniform; only the loader wave waits here)
+        SpinGuard sgr;
+        while (true) {
+            POLL_FENCE();
+            if (__hip_atomic_load(ready + (s % RING_STEPS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(s + 1)) break;
+            if (s_abort || !sgr.keep_waiting()) { s_abort = 1; *a.err = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
     auto loader_issue = [&](int s) {
         if (a.diag & 2) return;
-        const int t = step_t(s < T ? s : T - 1);
+        const int sc = s < T ? s : T - 1;
+        ring_wait(sc);
+        const float* slot = ring + (size_t)(sc % RING_STEPS) * FWD_STEP_FLOATS;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int cell = 64 * k + lane;
-            int b = bg * 16 + (cell >> 4); b = b < B ? b : B - 1;
-            dma16(a.gates + ((((size_t)t * B + b) * 2 + dir) * HID + 16 * g + (cell & 15)) * 4, &xin[s % FWD_RING][64 * k]);
+            dma16_sc1(slot + (cell >> 4) * 1024 + (16 * g + (cell & 15)) * 4, &xin[s % FWD_RING][64 * k]);
         }
     };
     auto io_store_results = [&](int s) {      // results of step s: 4 + 1 + 1 sixteen-byte stores per lane
@@ -358,10 +393,8 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
                 loader_issue(step + FWD_LEAD);
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * FWD_LEAD) : "memory");   // this step's rows have landed
             }
-            if (g == 0 && tid == 0) {   // paces the prefetcher; a plain store (shared L2) unless the cluster spans XCDs
-                if (same_xcd) *reinterpret_cast<volatile unsigned*>(a.progress + cl * 32) = (unsigned)step;
-                else __hip_atomic_store(a.progress + cl * 32, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (g == 0 && tid == 0)     // paces the helpers (which may sit on another XCD: agent-scope store)
+                __hip_atomic_store(a.progress + cl * 32, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             STAMP(0);
             if (w < IO_WAVE && step > 0) {
                 const unsigned pbase = (unsigned)((step - 1) & 1) * SLOT;
@@ -484,7 +517,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     const int cl = blockIdx.x % a.NCL8, g = blockIdx.x / a.NCL8;
     if (cl >= 2 * a.NBG) return;
     const int dir = cl & 1, bg = cl >> 1;
-    if (g == G_CLUSTER) { prefetcher_loop(a, cl, dir, bg, true); return; }
+    if (g >= G_CLUSTER) { helper_loop(a, cl, dir, bg, g - G_CLUSTER, true, nullptr); return; }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = lane >> 4, n = lane & 15;      // MFMA coordinates
     const int pu = tid & 15, pn = (tid >> 4) & 15;   // cell coordinates (unit fastest: coalesced partial reads)
@@ -527,19 +560,30 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     // ---- loader / storer: lane L serves cells 64k+L for the 16-byte gate rows and cells 4L..4L+3 for 4-byte rows
     auto step_t = [&](int s) { return dir ? s : T - 1 - s; };
     // 6 LDS-DMA instructions per step, ALWAYS issued (step and utterance clamped) so the counted wait is exact
+    const float* ring = a.ring + (size_t)cl * RING_STEPS * BWD_STEP_FLOATS;
+    const unsigned* ready = a.ready + (size_t)cl * 32;
+    auto ring_wait = [&](int s) {      // until the helpers have staged step s (wave-uniform; only the loader wave waits here)
+        SpinGuard sgr;
+        while (true) {
+            POLL_FENCE();
+            if (__hip_atomic_load(ready + (s % RING_STEPS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(s + 1)) break;
+            if (s_abort || !sgr.keep_waiting()) { s_abort = 1; *a.err = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
     auto loader_issue = [&](int s) {
-        const int t = step_t(s < T ? s : T - 1);
+        const int sc = s < T ? s : T - 1;
+        ring_wait(sc);
+        const float* rs_ = ring + (size_t)(sc % RING_STEPS) * BWD_STEP_FLOATS;
         const int slot = s % BWD_RING;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int cell = 64 * k + lane;
-            int b = bg * 16 + (cell >> 4); b = b < B ? b : B - 1;
-            dma16(a.gates + ((((size_t)t * B + b) * 2 + dir) * HID + 16 * g + (cell & 15)) * 4, &sg_[slot][64 * k]);
+            dma16_sc1(rs_ + (cell >> 4) * 1024 + (16 * g + (cell & 15)) * 4, &sg_[slot][64 * k]);
         }
         const int cell0 = 4 * lane, u0 = 16 * g + (cell0 & 15);
-        int b = bg * 16 + (cell0 >> 4); b = b < B ? b : B - 1;
-        dma16(a.cbuf + (((size_t)t * B + b) * 2 + dir) * HID + u0, &sct[slot][0]);
-        dma16(a.dout + ((size_t)t * B + b) * (2 * HID) + dir * HID + u0, &sdy[slot][0]);
+        dma16_sc1(rs_ + 16 * 1024 + (cell0 >> 4) * 256 + u0, &sct[slot][0]);
+        dma16_sc1(rs_ + 16 * 1024 + 16 * 256 + (cell0 >> 4) * 256 + u0, &sdy[slot][0]);
     };
     auto io_store_results = [&](int s) {
         const int t = step_t(s), par = s & 1;
@@ -558,10 +602,8 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     {
         for (int step = 0; step < T; ++step) {
             const int t = step_t(step);
-            if (g == 0 && tid == 0) {   // paces the prefetcher
-                if (same_xcd) *reinterpret_cast<volatile unsigned*>(a.progress + cl * 32) = (unsigned)step;
-                else __hip_atomic_store(a.progress + cl * 32, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (g == 0 && tid == 0)     // paces the helpers
+                __hip_atomic_store(a.progress + cl * 32, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             float4 d = make_float4(0, 0, 0, 0);
             unsigned short* dbuf = &dgl[(step & 1) * (16 * 2 * 64)];
             if (w == LOADER_WAVE) {
@@ -778,7 +820,7 @@ __global__ __launch_bounds__(256) void lstm_prepare_kernel(u32x4* head, unsigned
     for (unsigned i = i0; i < nx; i += stride) xbuf[i] = (u32x4){1u, 1u, 1u, 1u};
 }
 
-struct WsLayout { size_t err, hello, progress, xbuf, xbytes, stamps, total; int NBG, NCL8; };
+struct WsLayout { size_t err, hello, progress, ready, xbuf, xbytes, ring, stamps, total; int NBG, NCL8; };
 WsLayout lstm_ws_layout(int B, bool backward) {
     WsLayout l;
     l.NBG = (B + 15) / 16;
@@ -788,9 +830,11 @@ WsLayout lstm_ws_layout(int B, bool backward) {
     l.err = 0;                                   // 256 bytes
     l.hello = 256;                               // [clusters][16] words; err+hello zeroed every call
     l.progress = l.hello + pgasr_align_up((size_t)ncl * 16 * sizeof(unsigned), 256);   // one 128-B line per cluster
-    l.xbuf = l.progress + pgasr_align_up((size_t)ncl * 128, 256);
+    l.ready = l.progress + pgasr_align_up((size_t)ncl * 128, 256);                    // [cluster][32 words], zeroed every call
+    l.xbuf = l.ready + pgasr_align_up((size_t)ncl * 128, 256);
     l.xbytes = (size_t)ncl * 2 * slot;           // [cluster][parity][slot], filled with 0x00000001 every call
-    l.stamps = l.xbuf + l.xbytes;
+    l.ring = l.xbuf + l.xbytes;                  // [cluster][RING_STEPS][step floats]: staging ring of the helper workgroups
+    l.stamps = l.ring + (size_t)ncl * RING_STEPS * (backward ? BWD_STEP_FLOATS : FWD_STEP_FLOATS) * sizeof(float);
     l.total = l.stamps;
 #ifdef PGASR_LSTM_STAMPS
     l.total += (size_t)STAMP_MAX_T * 8 * sizeof(long long);
@@ -866,6 +910,7 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
     a.xbuf = (unsigned char*)(ws + l.xbuf); a.hello = (unsigned*)(ws + l.hello); a.err = (int*)(ws + l.err);
     a.busy = (unsigned*)(ws + l.err + 64);   // 8 words inside the zeroed 256-byte head block
     a.progress = (unsigned*)(ws + l.progress);
+    a.ring = (float*)(ws + l.ring); a.ready = (unsigned*)(ws + l.ready);
     a.lengths = lengths; a.T = T; a.B = B; a.NBG = l.NBG; a.NCL8 = l.NCL8;
     a.force_mode = (flags & 1) ? 1 : 0;
     a.diag = (flags >> 8) & 0xFFFF;
@@ -873,7 +918,7 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
 #ifdef PGASR_LSTM_STAMPS
     if (T > STAMP_MAX_T) return PGASR_ERR_UNSUPPORTED;
 #endif
-    dim3 grid((G_CLUSTER + 1) * l.NCL8);   // + one prefetcher workgroup per cluster
+    dim3 grid((G_CLUSTER + N_HELPERS) * l.NCL8);   // + the helper workgroups of each cluster
     if (backward) PGASR_LAUNCH_KERNEL(lstm_bwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
     else PGASR_LAUNCH_KERNEL(lstm_fwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
     PGASR_CHECK_LAUNCH();
