@@ -24,8 +24,21 @@ namespace {
 
 constexpr int HID = 256;           // hidden size per direction (model.py:40)
 constexpr int G_CLUSTER = 16;      // compute workgroups per (direction, batch group): 16 units each
-constexpr int N_HELPERS = 4;       // + helper workgroups per cluster that stage the sweep's HBM rows into a hot ring
-constexpr int RING_STEPS = 16;     // depth of that ring (steps)
+#ifndef PGASR_N_HELPERS
+#define PGASR_N_HELPERS 4
+#endif
+constexpr int N_HELPERS = PGASR_N_HELPERS;       // + helper workgroups per cluster that stage the sweep's HBM rows into a hot ring
+#ifndef PGASR_FWD_RING_STEPS
+#define PGASR_FWD_RING_STEPS 16
+#endif
+#ifndef PGASR_BWD_RING_STEPS
+#define PGASR_BWD_RING_STEPS 16
+#endif
+// ring depth per sweep (steps).  Stand-alone sweeps: forward 8 -> 1.15 us/step, 16 -> 1.23, 32 -> 1.33 (a smaller ring
+// stays in L2); backward 8 -> 1.71, 16 -> 1.62 (its loader runs 4 steps ahead and needs the slack).  Inside the train
+// step 8/16 and 16/16 measured the same (11.86 vs 11.82 ms), so both use 16.
+constexpr int FWD_RING_STEPS = PGASR_FWD_RING_STEPS, BWD_RING_STEPS = PGASR_BWD_RING_STEPS;
+constexpr int RING_STEPS_MAX = 32;     // depth of that ring (steps)
 constexpr int FWD_STEP_FLOATS = 16 * 1024;                           // 16 utterances x (256 units x 4 gates)
 constexpr int BWD_STEP_FLOATS = 16 * 1024 + 16 * 256 + 16 * 256;     // + c_t + dout
 constexpr int LSTM_THREADS = 384;     // 4 compute waves + loader wave + storer wave
@@ -64,7 +77,7 @@ struct LstmArgs {
     unsigned* hello;         // [clusters][16] start-up words (XCC id of each member), zeroed per call
     unsigned* progress;      // [clusters] current step of member 0 (paces the helpers), zeroed per call
     float* ring;             // [clusters][RING_STEPS][step floats]: the rows of the next steps, staged by the helper workgroups
-    unsigned* ready;         // [clusters][32]: words 0..15 = (step + 1) held by each ring slot (0 = nothing yet), zeroed per call
+    unsigned* ready;         // [clusters][32]: word i = (step + 1) held by ring slot i (0 = nothing yet), zeroed per call
     int* err;                // set to 1 when a bounded wait gives up
     unsigned* busy;          // [8] per-XCD count of clusters currently sweeping there (read by queue-mode GEMMs)
     const int* lengths;      // [B]
@@ -200,6 +213,7 @@ __device__ __forceinline__ void helper_loop(const LstmArgs& a, int cl, int dir, 
         same = !__any((v & 0xFu) != xcc) && a.force_mode == 0;
     }
     const int step_floats = backward ? BWD_STEP_FLOATS : FWD_STEP_FLOATS;
+    const int RING_STEPS = backward ? BWD_RING_STEPS : FWD_RING_STEPS;
     float* ring = a.ring + (size_t)cl * RING_STEPS * step_floats;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ring, 0, (int)(RING_STEPS * step_floats * 4), 0x00020000);
     unsigned* ready = a.ready + (size_t)cl * 32;
@@ -346,6 +360,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
     };
     // 4 LDS-DMA instructions per step, ALWAYS issued (step and utterance clamped into range) so that the
     // counted wait below is exact: vmcnt(4*FWD_LEAD) leaves only the loads of the next FWD_LEAD steps in flight
+    constexpr int RING_STEPS = FWD_RING_STEPS;
     const float* ring = a.ring + (size_t)cl * RING_STEPS * FWD_STEP_FLOATS;
     const unsigned* ready = a.ready + (size_t)cl * 32;
     auto ring_wait = [&](int s) {      // until the helpers have staged step s (wave-uniform; only the loader wave waits here)
@@ -560,6 +575,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     // ---- loader / storer: lane L serves cells 64k+L for the 16-byte gate rows and cells 4L..4L+3 for 4-byte rows
     auto step_t = [&](int s) { return dir ? s : T - 1 - s; };
     // 6 LDS-DMA instructions per step, ALWAYS issued (step and utterance clamped) so the counted wait is exact
+    constexpr int RING_STEPS = BWD_RING_STEPS;
     const float* ring = a.ring + (size_t)cl * RING_STEPS * BWD_STEP_FLOATS;
     const unsigned* ready = a.ready + (size_t)cl * 32;
     auto ring_wait = [&](int s) {      // until the helpers have staged step s (wave-uniform; only the loader wave waits here)
@@ -572,6 +588,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
         }
     };
     auto loader_issue = [&](int s) {
+        if (a.diag & 2) return;
         const int sc = s < T ? s : T - 1;
         ring_wait(sc);
         const float* rs_ = ring + (size_t)(sc % RING_STEPS) * BWD_STEP_FLOATS;
@@ -586,6 +603,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
         dma16_sc1(rs_ + 16 * 1024 + 16 * 256 + (cell0 >> 4) * 256 + u0, &sdy[slot][0]);
     };
     auto io_store_results = [&](int s) {
+        if (a.diag & 1) return;
         const int t = step_t(s), par = s & 1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -834,7 +852,7 @@ WsLayout lstm_ws_layout(int B, bool backward) {
     l.xbuf = l.ready + pgasr_align_up((size_t)ncl * 128, 256);
     l.xbytes = (size_t)ncl * 2 * slot;           // [cluster][parity][slot], filled with 0x00000001 every call
     l.ring = l.xbuf + l.xbytes;                  // [cluster][RING_STEPS][step floats]: staging ring of the helper workgroups
-    l.stamps = l.ring + (size_t)ncl * RING_STEPS * (backward ? BWD_STEP_FLOATS : FWD_STEP_FLOATS) * sizeof(float);
+    l.stamps = l.ring + (size_t)ncl * (backward ? BWD_RING_STEPS * BWD_STEP_FLOATS : FWD_RING_STEPS * FWD_STEP_FLOATS) * sizeof(float);
     l.total = l.stamps;
 #ifdef PGASR_LSTM_STAMPS
     l.total += (size_t)STAMP_MAX_T * 8 * sizeof(long long);
