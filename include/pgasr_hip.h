@@ -206,7 +206,8 @@ int pgasr_log_softmax_rows(const float* logits, long long rows, int V, float* lo
  *   pgasr_gemm_f32 and maps them back with pgasr_lstm_unpack_grads.  dbias_part (optional, 16-byte aligned,
  *   ceil(B/16) x 2*4H floats): per 16-utterance group, the sum over t of dgates in gates' column order -- the bias
  *   gradient is the sum of its rows (saves a 262 MB column-sum pass over dgates at B=32,T=1000).
- * The sweeps are persistent kernels: 16 workgroups per (direction, 16-utterance group) that hand
+ * The sweeps are persistent kernels: 16 compute workgroups (+ 4 helper workgroups that stage the coming steps'
+ * HBM rows in an L2-resident ring inside the workspace) per (direction, 16-utterance group) that hand
  * h_t / partial dh sums to each other through global memory every step (self-validating words; plain
  * stores when the cluster is verified to share an XCD, write-through stores otherwise).
  * flags bit 0: force the write-through protocol (testing the placement-independent path).

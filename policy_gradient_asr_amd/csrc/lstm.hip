@@ -18,6 +18,10 @@
 // blockIdx % 8 (one XCD under the observed round-robin dispatch); the members check at run time
 // (HW_REG_XCC_ID) whether they really share an XCD and then publish with plain stores that stay
 // in that XCD's L2, otherwise with write-through (sc1) stores.  Loads always bypass L1 (sc1).
+// The rows a step needs from HBM (xproj / saved activations, c_t, dout) never enter a compute
+// workgroup's memory pipeline cold: N_HELPERS helper workgroups per cluster copy them, steps
+// ahead, into an L2-resident ring inside the workspace (helper_loop below); the compute
+// workgroups' loader waves DMA from that ring.
 #include "common.h"
 
 namespace {
