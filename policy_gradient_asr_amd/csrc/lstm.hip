@@ -82,6 +82,7 @@ struct LstmArgs {
     unsigned* progress;      // [clusters] current step of member 0 (paces the helpers), zeroed per call
     float* ring;             // [clusters][RING_STEPS][step floats]: the rows of the next steps, staged by the helper workgroups
     unsigned* ready;         // [clusters][32]: word i = (step + 1) held by ring slot i (0 = nothing yet), zeroed per call
+    int n_helpers;           // helper workgroups per cluster: N_HELPERS, or 0 when two clusters must share an XCD (B > 64)
     int* err;                // set to 1 when a bounded wait gives up
     unsigned* busy;          // [8] per-XCD count of clusters currently sweeping there (read by queue-mode GEMMs)
     const int* lengths;      // [B]
@@ -382,6 +383,16 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
     auto loader_issue = [&](int s) {
         if (a.diag & 2) return;
         const int sc = s < T ? s : T - 1;
+        if (a.n_helpers == 0) {      // no room for helpers (two clusters per XCD): straight from HBM, the slower way
+            const int t = step_t(sc);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cell = 64 * k + lane;
+                int b = bg * 16 + (cell >> 4); b = b < B ? b : B - 1;
+                dma16(a.gates + ((((size_t)t * B + b) * 2 + dir) * HID + 16 * g + (cell & 15)) * 4, &xin[s % FWD_RING][64 * k]);
+            }
+            return;
+        }
         ring_wait(sc);
         const float* slot = ring + (size_t)(sc % RING_STEPS) * FWD_STEP_FLOATS;
 #pragma unroll
@@ -597,9 +608,23 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     auto loader_issue = [&](int s) {
         if (a.diag & 2) return;
         const int sc = s < T ? s : T - 1;
+        const int slot = s % BWD_RING;
+        if (a.n_helpers == 0) {      // no room for helpers (two clusters per XCD): straight from HBM, the slower way
+            const int t = step_t(sc);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cell = 64 * k + lane;
+                int b = bg * 16 + (cell >> 4); b = b < B ? b : B - 1;
+                dma16(a.gates + ((((size_t)t * B + b) * 2 + dir) * HID + 16 * g + (cell & 15)) * 4, &sg_[slot][64 * k]);
+            }
+            const int cell0 = 4 * lane, u0 = 16 * g + (cell0 & 15);
+            int b = bg * 16 + (cell0 >> 4); b = b < B ? b : B - 1;
+            dma16(a.cbuf + (((size_t)t * B + b) * 2 + dir) * HID + u0, &sct[slot][0]);
+            dma16(a.dout + ((size_t)t * B + b) * (2 * HID) + dir * HID + u0, &sdy[slot][0]);
+            return;
+        }
         ring_wait(sc);
         const float* rs_ = ring + (size_t)(sc % RING_STEPS) * BWD_STEP_FLOATS;
-        const int slot = s % BWD_RING;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int cell = 64 * k + lane;
@@ -949,7 +974,11 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
 #ifdef PGASR_LSTM_STAMPS
     if (T > STAMP_MAX_T) return PGASR_ERR_UNSUPPORTED;
 #endif
-    dim3 grid((G_CLUSTER + N_HELPERS) * l.NCL8);   // + the helper workgroups of each cluster
+    // Helpers are not optional once the loaders wait for them, and this kernel gets at most one cluster's worth of
+    // extra workgroups onto an XCD that already holds a cluster (measured: B = 80 deadlocked until the time-outs
+    // with 2 x 20 workgroups on one XCD): with more than 8 clusters the loaders read HBM themselves, as before.
+    a.n_helpers = (2 * l.NBG <= 8) ? N_HELPERS : 0;
+    dim3 grid((G_CLUSTER + a.n_helpers) * l.NCL8);   // + the helper workgroups of each cluster
     if (backward) PGASR_LAUNCH_KERNEL(lstm_bwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
     else PGASR_LAUNCH_KERNEL(lstm_fwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
     PGASR_CHECK_LAUNCH();

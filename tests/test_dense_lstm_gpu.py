@@ -131,6 +131,7 @@ def _lstm_case(T, B, lens, seed, in_dim=512):
     (1, 5, [1] * 5),                                # a single frame: no recurrent exchange at all
     (3, 17, [3] * 9 + [1] * 8),                     # one utterance over a 16-utterance group: a second, nearly empty cluster pair
     (7, 48, [7] * 20 + [4] * 28),                   # three groups = six clusters
+    (5, 80, [5] * 50 + [2] * 30),                   # ten clusters: two share an XCD, no room for helper workgroups
 ])
 def test_blstm_layer_vs_torch_cpu(T, B, lens):
     from policy_gradient_asr_amd import functional as Fh
