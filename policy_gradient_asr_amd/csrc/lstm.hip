@@ -727,32 +727,38 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
                     Dhi[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&dbuf[(n * 2 + 0) * 64 + 32 * i + 8 * q]));
                     Dlo[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&dbuf[(n * 2 + 1) * 64 + 32 * i + 8 * q]));
                 }
-                f32x4 acc[4];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[mt][i], Dhi[i], acc[mt], 0, 0, 0);
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[mt][i], Dlo[i], acc[mt], 0, 0, 0);
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wlo[mt][i], Dhi[i], acc[mt], 0, 0, 0);
-                }
                 const unsigned e = (unsigned)(step >> 1) & 1u;
                 const unsigned tag = e ? 0x1u : 0x2u;       // (bit0, bit1) = (e, 1-e)
                 const unsigned obase = (unsigned)(step & 1) * SLOT + (unsigned)g * (16 * 256 * 4);
+                // two tile pairs: the first pair is on its way to L2 while the second is still being multiplied (the
+                // 16 KiB this workgroup publishes per step is the start of everybody else's hand-off)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    u32x4 o;
-                    o.x = (__float_as_uint(acc[mt][0]) & ~3u) | tag;
-                    o.y = (__float_as_uint(acc[mt][1]) & ~3u) | tag;
-                    o.z = (__float_as_uint(acc[mt][2]) & ~3u) | tag;
-                    o.w = (__float_as_uint(acc[mt][3]) & ~3u) | tag;
-                    // lane (q,n), tile 4w+mt: output units 16(4w+mt) + 4q .. +3 for utterance n
-                    const unsigned off = obase + (unsigned)((n * 256 + 16 * (4 * w + mt) + 4 * q) * 4);
-                    if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 0);
-                    else          __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 16);
+                for (int half = 0; half < 2; ++half) {
+                    f32x4 acc[2];
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; ++m2) acc[m2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                        for (int m2 = 0; m2 < 2; ++m2) acc[m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[2 * half + m2][i], Dhi[i], acc[m2], 0, 0, 0);
+#pragma unroll
+                        for (int m2 = 0; m2 < 2; ++m2) acc[m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[2 * half + m2][i], Dlo[i], acc[m2], 0, 0, 0);
+#pragma unroll
+                        for (int m2 = 0; m2 < 2; ++m2) acc[m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wlo[2 * half + m2][i], Dhi[i], acc[m2], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; ++m2) {
+                        const int mt = 2 * half + m2;
+                        u32x4 o;
+                        o.x = (__float_as_uint(acc[m2][0]) & ~3u) | tag;
+                        o.y = (__float_as_uint(acc[m2][1]) & ~3u) | tag;
+                        o.z = (__float_as_uint(acc[m2][2]) & ~3u) | tag;
+                        o.w = (__float_as_uint(acc[m2][3]) & ~3u) | tag;
+                        // lane (q,n), tile 4w+mt: output units 16(4w+mt) + 4q .. +3 for utterance n
+                        const unsigned off = obase + (unsigned)((n * 256 + 16 * (4 * w + mt) + 4 * q) * 4);
+                        if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 0);
+                        else          __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 16);
+                    }
                 }
             }
         }
