@@ -662,6 +662,16 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
                 loader_issue(step + BWD_LEAD);
                 asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             } else if (w < IO_WAVE) {
+                // everything that does not need the incoming dh is done BEFORE the poll (the rows of this step have
+                // been in the LDS ring since the previous barrier): after the hand-off only five multiply-adds remain
+                const bool active = t < len;
+                const float4 gt = sg_[step % BWD_RING][tid];
+                const float ct = sct[step % BWD_RING][tid], dy = sdy[step % BWD_RING][tid];
+                const float cp = (step + 1 < T) ? sct[(step + 1) % BWD_RING][tid] : 0.f;
+                const float gi = gt.x, gf = gt.y, gg = gt.z, go = gt.w;
+                const float tc = tanhf_fast(ct);
+                const float k_c = go * (1.f - tc * tc);          // d(dh) -> d(c)
+                const float k_i = gg * gi * (1.f - gi), k_f = cp * gf * (1.f - gf), k_g = gi * (1.f - gg * gg), k_o = tc * go * (1.f - go);
                 float dh_rec = carry;
                 if (step > 0) {
                     const unsigned pbase = (unsigned)((step - 1) & 1) * SLOT + (unsigned)((pn * 256 + unit) * 4);
@@ -691,18 +701,12 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
                     for (int s = 0; s < 16; ++s) sum += v[s];     // fixed order: reproducible
                     dh_rec += sum;
                 }
-                const bool active = t < len;
-                const float4 gt = sg_[step % BWD_RING][tid];
-                const float ct = sct[step % BWD_RING][tid], dy = sdy[step % BWD_RING][tid];
-                const float cp = (step + 1 < T) ? sct[(step + 1) % BWD_RING][tid] : 0.f;
-                const float gi = gt.x, gf = gt.y, gg = gt.z, go = gt.w;
                 const float dh = dy + dh_rec;
-                const float tc = tanhf_fast(ct);
-                const float dct = dh * go * (1.f - tc * tc) + dc;
-                d.x = dct * gg * gi * (1.f - gi);
-                d.y = dct * cp * gf * (1.f - gf);
-                d.z = dct * gi * (1.f - gg * gg);
-                d.w = dh * tc * go * (1.f - go);
+                const float dct = dh * k_c + dc;
+                d.x = dct * k_i;
+                d.y = dct * k_f;
+                d.z = dct * k_g;
+                d.w = dh * k_o;
                 if (active) { dc = dct * gf; carry = 0.f; }
                 else { d = make_float4(0, 0, 0, 0); carry = dh_rec; }
                 dbs.x += d.x; dbs.y += d.y; dbs.z += d.z; dbs.w += d.w;
