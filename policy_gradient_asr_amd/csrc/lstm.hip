@@ -580,7 +580,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
             }
         }
     }
-    constexpr unsigned SLOT = 16 * 16 * 256 * 4;      // [src 16][n 16][unit 256] fp32 = 256 KiB
+    constexpr unsigned SLOT = 16 * 16 * 256 * 4;      // [src 16][dst 16][n 16][unit 16] fp32 = 256 KiB
     unsigned char* xb = a.xbuf + (size_t)cl * (2 * SLOT);
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)(2 * SLOT), 0x00020000);
     const bool same_xcd = cluster_same_xcd(a, cl, g, tid, &s_same, &s_abort);
@@ -674,7 +674,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
                 const float k_i = gg * gi * (1.f - gi), k_f = cp * gf * (1.f - gf), k_g = gi * (1.f - gg * gg), k_o = tc * go * (1.f - go);
                 float dh_rec = carry;
                 if (step > 0) {
-                    const unsigned pbase = (unsigned)((step - 1) & 1) * SLOT + (unsigned)((pn * 256 + unit) * 4);
+                    // slot layout [src 16][dst 16][n 16][16 units]: what one member reads from one source is ONE contiguous KiB
+                    // (a wave's load = 256 contiguous bytes), and what a wave publishes for one destination as well
+                    const unsigned pbase = (unsigned)((step - 1) & 1) * SLOT + (unsigned)((g * 256 + pn * 16 + pu) * 4);
                     const unsigned stale_bit = (((step - 1) >> 1) & 1) ? 0x2u : 0x1u;
                     float v[16];
                     SpinGuard sg;
@@ -760,7 +762,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
                         o.z = (__float_as_uint(acc[m2][2]) & ~3u) | tag;
                         o.w = (__float_as_uint(acc[m2][3]) & ~3u) | tag;
                         // lane (q,n), tile 4w+mt: output units 16(4w+mt) + 4q .. +3 for utterance n
-                        const unsigned off = obase + (unsigned)((n * 256 + 16 * (4 * w + mt) + 4 * q) * 4);
+                        const unsigned off = obase + (unsigned)(((4 * w + mt) * 256 + n * 16 + 4 * q) * 4);
                         if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 0);
                         else          __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 16);
                     }
