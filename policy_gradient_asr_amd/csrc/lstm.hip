@@ -294,7 +294,7 @@ constexpr int LOADER_WAVE = 4, STORER_WAVE = 5;
 constexpr int FWD_LEAD = PGASR_FWD_LEAD, FWD_RING = FWD_LEAD + 2;   // loader runs FWD_LEAD steps ahead; ring slot reuse distance > lead + 1
 constexpr int BWD_LEAD = 4, BWD_RING = 6;
 #ifndef PGASR_BWD_POLL_DELAY
-#define PGASR_BWD_POLL_DELAY 8
+#define PGASR_BWD_POLL_DELAY 2
 #endif
 
 // the same with the agent-scope (L1-bypassing) policy: for data another workgroup has just written
@@ -684,7 +684,8 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
                     // poll is 16 KiB per workgroup through the L2 that the other members' 16-KiB publishes are still
                     // entering: hold the first poll back (x64 cycles).  Measured stand-alone 0: 1.61, 6: 1.59, 8: 1.55,
                     // 10: 1.52-1.57, 14: 1.61 us per step; train step 11.82 -> 11.64 ms with 10.  Re-measured after the dh-independent
-                    // cell work moved in front of the poll: 6: 1.42, 8: 1.41, 10: 1.45, 12: 1.50, 14: 1.55 -> 8.  (The forward sweep
+                    // cell work moved in front of the poll: 6: 1.42, 8: 1.41, 10: 1.45, 12: 1.50, 14: 1.55; and again with the
+                    // [src][dst][n][unit] slot layout (publishes land sooner): 0-4: 1.26-1.30, 6: 1.32, 8: 1.37, 10: 1.43 -> 2.  (The forward sweep
                     // publishes 1 KiB per member and only loses from a delay: 1.15 -> 1.19 / 1.30 / 1.37 for 4 / 8 / 12.)
                     __builtin_amdgcn_s_sleep(PGASR_BWD_POLL_DELAY);
                     while (true) {
