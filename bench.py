@@ -101,6 +101,8 @@ def main():
     torch.cuda.set_device(dev)
 
     from policy_gradient_asr_amd import hipops
+    if rehearse:
+        hipops.LSTM_FLAGS |= 4      # ranks share one GPU here: two sweeps' clusters per XCD leave no room for helper workgroups
     from policy_gradient_asr_amd.model import Seq2Seq, weights
     from policy_gradient_asr_amd.train_step import PolicyGradientTrainer
 

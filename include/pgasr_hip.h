@@ -210,7 +210,8 @@ int pgasr_log_softmax_rows(const float* logits, long long rows, int V, float* lo
  * HBM rows in an L2-resident ring inside the workspace) per (direction, 16-utterance group) that hand
  * h_t / partial dh sums to each other through global memory every step (self-validating words; plain
  * stores when the cluster is verified to share an XCD, write-through stores otherwise).
- * flags bit 0: force the write-through protocol (testing the placement-independent path).
+ * flags bit 0: force the write-through protocol (testing the placement-independent path); bit 2: no helper
+ * workgroups (the loaders read HBM themselves: slower, but two processes can then share one GPU's XCDs).
  * Limit: B <= 128.  workspace (pgasr_lstm_workspace_bytes) holds exchange buffers and an
  * error word (offset: pgasr_lstm_error_offset) that is set when a bounded wait times out.
  * ---------------------------------------------------------------------------------------- */

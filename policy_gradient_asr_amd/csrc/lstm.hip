@@ -991,7 +991,7 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
     // Helpers are not optional once the loaders wait for them, and this kernel gets at most one cluster's worth of
     // extra workgroups onto an XCD that already holds a cluster (measured: B = 80 deadlocked until the time-outs
     // with 2 x 20 workgroups on one XCD): with more than 8 clusters the loaders read HBM themselves, as before.
-    a.n_helpers = (2 * l.NBG <= 8) ? N_HELPERS : 0;
+    a.n_helpers = (2 * l.NBG <= 8 && !(flags & 4)) ? N_HELPERS : 0;      // flags bit 2: no helpers (two processes sharing one GPU)
     dim3 grid((G_CLUSTER + a.n_helpers) * l.NCL8);   // + the helper workgroups of each cluster
     if (backward) PGASR_LAUNCH_KERNEL(lstm_bwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
     else PGASR_LAUNCH_KERNEL(lstm_fwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
