@@ -212,6 +212,9 @@ int pgasr_log_softmax_rows(const float* logits, long long rows, int V, float* lo
  * stores when the cluster is verified to share an XCD, write-through stores otherwise).
  * flags bit 0: force the write-through protocol (testing the placement-independent path); bit 2: no helper
  * workgroups (the loaders read HBM themselves: slower, but two processes can then share one GPU's XCDs).
+ * All workgroups of a sweep wait for each other and must be co-resident: with helpers a sweep takes 20 of an XCD's 32
+ * CUs per cluster, so run ONE sweep at a time per GPU (other kernels beside it are fine: they finish on their own) or
+ * set bit 2.  Every wait is bounded (3 s): a sweep that cannot make progress sets the error word and returns.
  * Limit: B <= 128.  workspace (pgasr_lstm_workspace_bytes) holds exchange buffers and an
  * error word (offset: pgasr_lstm_error_offset) that is set when a bounded wait times out.
  * ---------------------------------------------------------------------------------------- */
