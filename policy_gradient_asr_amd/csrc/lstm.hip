@@ -239,7 +239,7 @@ __device__ __forceinline__ void helper_loop(const LstmArgs& a, int cl, int dir, 
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
             int b = bg * 16 + n; b = b < B ? b : B - 1;
-            v[n] = *reinterpret_cast<const u32x4*>(a.gates + ((((size_t)t * B + b) * 2 + dir) * HID) * 4 + w * 256 + lane * 4);
+            v[n] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.gates + ((((size_t)t * B + b) * 2 + dir) * HID) * 4 + w * 256 + lane * 4));   // streamed once: should not displace the ring in L2
         }
         u32x4 vc[4], vd[4];
         if (backward) {
@@ -247,8 +247,8 @@ __device__ __forceinline__ void helper_loop(const LstmArgs& a, int cl, int dir, 
             for (int j = 0; j < 4; ++j) {
                 const int i = j * 256 + tid;                  // 16-byte chunk of the 16 x 256 floats
                 int b = bg * 16 + (i >> 6); b = b < B ? b : B - 1;
-                vc[j] = *reinterpret_cast<const u32x4*>(a.cbuf + (((size_t)t * B + b) * 2 + dir) * HID + (i & 63) * 4);
-                vd[j] = *reinterpret_cast<const u32x4*>(a.dout + ((size_t)t * B + b) * (2 * HID) + dir * HID + (i & 63) * 4);
+                vc[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.cbuf + (((size_t)t * B + b) * 2 + dir) * HID + (i & 63) * 4));
+                vd[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.dout + ((size_t)t * B + b) * (2 * HID) + dir * HID + (i & 63) * 4));
             }
         }
         const int aux = same ? 0 : 16;
