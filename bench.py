@@ -113,8 +113,8 @@ def main():
     trainer = PolicyGradientTrainer(model, lr=5e-4, lam=1.0, seed=1234, world_size=world, rank=rank)
     if rehearse and world > 1:
         _ar = dist.all_reduce
-        def _cpu_all_reduce(t, op=dist.ReduceOp.SUM, group=None):   # gloo has no device tensors here
-            c = t.cpu(); _ar(c, op=op, group=group); t.copy_(c)
+        def _cpu_all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):   # gloo has no device tensors here
+            c = t.cpu(); _ar(c, op=op, group=group); t.copy_(c)                      # (synchronous either way)
         dist.all_reduce = _cpu_all_reduce
         _bc = dist.broadcast
         def _cpu_broadcast(t, src=0, group=None):

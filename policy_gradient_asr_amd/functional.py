@@ -37,6 +37,7 @@ class grad_overlap:
             cls._sides[k] = torch.cuda.Stream()
         return cls._sides[k]
 
+    upper_grads_hook = None   # callable(swept_event): called by the FIRST layer's backward once every gradient above it is issued
     split_tail = True  # no sweep follows the first layer's backward: run its dW_hh beside its dW_ih
     _sides2 = {}
 
@@ -257,6 +258,10 @@ class BLSTMLayerFn(torch.autograd.Function):
             grad_overlap.flush(hipops.lstm_busy_ptr(T, B, True, dev), launched_after=before)
             swept = torch.cuda.Event()
             swept.record()
+            if not ctx.sweep_follows and grad_overlap.upper_grads_hook is not None:
+                # first layer: the head's and the upper layers' weight gradients are all on the side stream now
+                # (N > 1: the trainer starts their all-reduce there, behind this sweep and under the tail GEMMs)
+                grad_overlap.upper_grads_hook(swept)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(T, B, I, dtype=torch.float32, device=dev)

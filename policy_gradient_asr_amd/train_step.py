@@ -7,6 +7,8 @@ optimizer is one Adam over the flat buffer.  Utterances are independent through 
 decode, reward and REINFORCE gradient, so the gradient all-reduce is the only collective; the loss
 is normalised by the GLOBAL batch so 1-GPU and N-GPU gradients agree to fp32 rounding.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -77,8 +79,41 @@ class DataParallelStep:
         else:   # CPU is only the gloo plumbing test: torch's Adam
             self.opt = torch.optim.Adam([self.flat_param], lr=lr)
         self.nstep = 0
+        self.collective = self.world > 1    # tests set this on a 1-rank group to exercise the plumbing
+        self._early = None                  # (split, work) of an all-reduce issued during backward
         if self.world > 1:
             dist.broadcast(self.flat, src=0, group=self.pg)   # identical replicas
+
+    def param_offset(self, name):
+        """Offset in the flat buffers of the parameter called ``name`` (model.named_parameters() order)."""
+        off = 0
+        for n, p in self.model.named_parameters():
+            if n == name:
+                return off
+            off += p.numel()
+        raise KeyError(name)
+
+    def reduce_upper(self, split):
+        """Start the all-reduce of gflat[split:] now (its gradients are complete on the CURRENT stream) and leave
+        gflat[:split] to ``reduce_rest``: two buckets, the first one hidden under what is left of backward.
+        Every rank must call it at the same point of its step (collectives are matched by order)."""
+        if not self.collective or self._early is not None:
+            return
+        work = dist.all_reduce(self.gflat[split:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._early = (split, work)
+
+    def reduce_rest(self):
+        if not self.collective:
+            return
+        if self._early is None:
+            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.pg)
+            return
+        split, work = self._early
+        self._early = None
+        if work is not None:
+            work.wait()                 # the current stream waits for the first bucket
+        if split > 0:
+            dist.all_reduce(self.gflat[:split], op=dist.ReduceOp.SUM, group=self.pg)
 
     def forward_loss(self, batch, global_batch):  # pragma: no cover - abstract
         raise NotImplementedError
@@ -91,8 +126,7 @@ class DataParallelStep:
         self.gflat.zero_()
         loss = self.forward_loss(batch, local_b * self.world)
         self.backward(loss)
-        if self.world > 1:
-            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.pg)
+        self.reduce_rest()
         self.nstep += 1
         if self.opt is None:
             from . import hipops
@@ -116,15 +150,35 @@ class PolicyGradientTrainer(DataParallelStep):
         self.blank = blank
         self.last_stats = None
         self.overlap_weight_grads = True
+        # N > 1: the gradients of the head and of BLSTM layers 1, 2 (2/3 of the bytes) are all-reduced under the tail
+        # of backward (the first layer's three GEMMs and the affine gradients), the rest after it
+        self.early_reduce = os.environ.get("PGASR_EARLY_REDUCE", "1") != "0"
+        try:
+            self.upper_split = self.param_offset("encoder.blstm.weight_ih_l1")
+        except KeyError:
+            self.upper_split = None
+
+    def _upper_grads_issued(self, swept):
+        """Called from the first BLSTM layer's backward once its sweep has been launched: every gradient of
+        gflat[upper_split:] has been issued on the side stream by then.  The collective is ordered after them AND
+        after the sweep (``swept``): a collective kernel never runs beside a sweep's latency chain."""
+        from .functional import grad_overlap
+        side = grad_overlap.side_stream()
+        with torch.cuda.stream(side):
+            side.wait_event(swept)
+            self.reduce_upper(self.upper_split)
 
     def backward(self, loss):
         """Weight-gradient GEMMs run on a side stream under the next layer's backward sweep."""
         from .functional import grad_overlap
         grad_overlap.enabled = self.overlap_weight_grads
+        early = self.collective and self.early_reduce and self.overlap_weight_grads and self.upper_split is not None
+        grad_overlap.upper_grads_hook = self._upper_grads_issued if early else None
         try:
             loss.backward()
         finally:
             grad_overlap.enabled = False
+            grad_overlap.upper_grads_hook = None
             grad_overlap.finish()
 
     def forward_loss(self, batch, global_batch):

@@ -20,6 +20,15 @@ class ToyStep(DataParallelStep):
         return ((self.model(x) - y) ** 2).sum() / global_batch
 
 
+class ToyStepTwoBuckets(ToyStep):
+    """The N>1 trainer's bucket split: the upper bucket's all-reduce is started (async) before the lower one."""
+
+    def backward(self, loss):
+        loss.backward()
+        self.reduce_upper(self.param_offset("2.weight"))
+        assert self._early is not None and self._early[0] == 6 * 5 + 5
+
+
 def make_model():
     torch.manual_seed(0)
     return torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
@@ -30,7 +39,7 @@ def make_data():
     return torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, two_buckets):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -39,7 +48,7 @@ def _worker(rank, world, port, q):
             with torch.no_grad():
                 for p in model.parameters():
                     p.add_(1.0)
-        st = ToyStep(model, lr=1e-2, world_size=world)
+        st = (ToyStepTwoBuckets if two_buckets else ToyStep)(model, lr=1e-2, world_size=world)
         x, y = make_data()
         sl = shard_slice(8, rank, world)
         losses = [float(st.step(x[sl], y[sl])) for _ in range(3)]
@@ -52,12 +61,13 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def test_two_rank_gloo_matches_single_process():
+@pytest.mark.parametrize("two_buckets", [False, True])
+def test_two_rank_gloo_matches_single_process(two_buckets):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, two_buckets)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])

@@ -197,6 +197,66 @@ def test_weight_grad_overlap_gives_identical_gradients():
     assert torch.equal(grads[0], grads[1])
 
 
+def _trainer_and_batch(seed=3, train=False):
+    from policy_gradient_asr_amd.model import Seq2Seq, weights
+    from policy_gradient_asr_amd.train_step import PolicyGradientTrainer
+    B, F, T, V, L = 20, 80, 60, 29, 6
+    x, targets, fmask, tmask = _make(B, F, T, V, L, [60] * 10 + [41] * 10, [6] * 20, seed)
+    torch.manual_seed(0)
+    m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(DEV)
+    m = m.train() if train else m.eval()
+    tr = PolicyGradientTrainer(m, lr=1e-3, lam=1.0, seed=5)
+    return tr, tuple(t.to(DEV) for t in (x, targets, fmask, tmask))
+
+
+def test_upper_bucket_is_complete_where_its_allreduce_is_issued():
+    """N>1 ordering (train_step.PolicyGradientTrainer._upper_grads_issued): at the point of the side stream where the
+    first bucket's all-reduce is enqueued, the gradients of the head and of BLSTM layers 1 and 2 are final.  The
+    collective is replaced by a snapshot taken in stream order at exactly that point."""
+    tr, batch = _trainer_and_batch(train=True)
+    snaps = []
+    tr.collective = True
+    tr.reduce_upper = lambda split: snaps.append((split, tr.gflat[split:].clone()))
+    tr.reduce_rest = lambda: None
+    for _ in range(3):
+        tr.step(*batch)
+        torch.cuda.synchronize()
+        split, snap = snaps.pop()
+        assert not snaps
+        assert split == tr.param_offset("encoder.blstm.weight_ih_l1") == 512 * 80 + 512 + 2 * (1024 * (512 + 256) + 2048)
+        assert torch.equal(snap, tr.gflat[split:])
+        assert float(snap.abs().sum()) > 0 and float(tr.gflat[:split].abs().sum()) > 0
+
+
+def test_two_bucket_allreduce_on_a_single_rank_rccl_group():
+    """The same path with real RCCL collectives on a 1-rank group (all-reduce = identity): both buckets are issued,
+    the async work is waited for before Adam, and parameters equal the collective-free trainer's bit for bit."""
+    import socket
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        flats = []
+        for collective in (False, True):
+            tr, batch = _trainer_and_batch(train=True)
+            tr.collective = collective
+            calls = []
+            if collective:
+                orig = tr.reduce_upper
+                def counted(split, orig=orig, calls=calls):
+                    calls.append(split); orig(split)
+                tr.reduce_upper = counted
+            for _ in range(3):
+                tr.step(*batch)
+            torch.cuda.synchronize()
+            assert tr._early is None
+            assert len(calls) == (3 if collective else 0)
+            flats.append(tr.flat.clone())
+        assert torch.equal(flats[0], flats[1])
+    finally:
+        dist.destroy_process_group()
+
+
 def test_train_mode_step_runs_with_dropout():
     from policy_gradient_asr_amd.model import Seq2Seq, weights
     from policy_gradient_asr_amd.train_step import PolicyGradientTrainer
