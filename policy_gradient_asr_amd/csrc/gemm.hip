@@ -304,6 +304,56 @@ __device__ __forceinline__ void xstore_strip(unsigned short* hi, unsigned short*
     }
 }
 
+// ---- TN products (both operands K x M/N with the M/N index contiguous: the weight gradients dW = dY^T X) ----
+// The LDS image keeps the global orientation, [k][128 m/n + 32 pad] bf16, and the MFMA fragments (8 consecutive k of
+// one row) come out of gfx950's transposing read ds_read_b64_tr_b16: the global loads are coalesced along m/n
+// (a half-wave reads 512 contiguous bytes of one k row), the staging writes are 8-byte (the [row][k] image above
+// needs 32 two-byte writes per strip and reads 16 bytes from each of 64 different lines per load instruction).
+// Pitch 160 halfs = 320 B = 64 mod 256: the four k rows of a half-wave's two 4 x 16 blocks cover all 64 banks once.
+constexpr int TPITCH = 160;
+static_assert(XBK * TPITCH == BM * XPITCH, "both LDS images fill the same array");
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+
+// thread -> (k = (tid>>5) + 8 i, 4 consecutive m/n from (tid&31)*4), i = 0..3
+__device__ __forceinline__ void tload_strip(const float* __restrict__ P, int ld, int mn_base, int mn_lim,
+                                            int k_base, int k_lim, int tid, bool vec_ok, float v[16]) {
+    const int mn0 = mn_base + (tid & 31) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k_base + (tid >> 5) + 8 * i;
+        if (k < k_lim && mn0 + 4 <= mn_lim && vec_ok) {
+            const float4 a = *reinterpret_cast<const float4*>(P + (size_t)k * ld + mn0);
+            v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[4 * i + c] = (k < k_lim && mn0 + c < mn_lim) ? P[(size_t)k * ld + mn0 + c] : 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void tstore_strip(unsigned short* hi, unsigned short* lo, int tid, const float v[16]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned h0, l0, h1, l1;
+        split2(v[4 * i], v[4 * i + 1], h0, l0);
+        split2(v[4 * i + 2], v[4 * i + 3], h1, l1);
+        const int o = ((tid >> 5) + 8 * i) * TPITCH + (tid & 31) * 4;
+        *reinterpret_cast<u32x2_t*>(hi + o) = (u32x2_t){h0, h1};
+        *reinterpret_cast<u32x2_t*>(lo + o) = (u32x2_t){l0, l1};
+    }
+}
+
+// 8 consecutive k (two 4 x 16 blocks) of this lane's row: ``p`` points at the lane's Mechanism address of the first
+// block (row k0 + q, columns 4p..4p+3 of the lane group's 16), the second block is 4 k rows further down
+__device__ __forceinline__ bf16x8_t tr_frag(const unsigned short* p) {
+    typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_ptr;
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * TPITCH));
+    return __builtin_bit_cast(bf16x8_t, (s16x8_t){a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w});
+}
+
 template <bool TA, bool TB, bool QUEUE>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(GemmArgs g) {
     // [buffer][operand A/B][plane hi/lo][128 rows][XPITCH]
@@ -356,12 +406,25 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(GemmArgs g
     // s_waitcnt: rocprofv3 SQ_WAIT_ANY, profiles/r01_gemm_pmc.txt).
     float ra0[16], rb0[16], ra1[16], rb1[16];
     const int fr = lane & 31, fk = (lane >> 5) * 8;
+    constexpr bool TNL = TA && !TB;      // transposing-read LDS image (see tload_strip)
+    // lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3 of the group's 4 x 16 block; groups 0,1 take
+    // columns 0-15 / 16-31 of k 0-7, groups 2,3 the same columns of k 8-15 (= the 32x32x16 operand map)
+    const int tro = (8 * (lane >> 5) + ((lane & 15) >> 2)) * TPITCH + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     auto compute = [&](int cur) {
 #pragma unroll
         for (int kk = 0; kk < XBK; kk += 16) {
             bf16x8_t ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+                if constexpr (TNL) {
+                    const int ro = kk * TPITCH + wm * 64 + i * 32 + tro;
+                    ah[i] = tr_frag(&S[cur][0][0][ro]);
+                    al[i] = tr_frag(&S[cur][0][1][ro]);
+                    const int co = kk * TPITCH + wn * 64 + i * 32 + tro;
+                    bh[i] = tr_frag(&S[cur][1][0][co]);
+                    bl[i] = tr_frag(&S[cur][1][1][co]);
+                    continue;
+                }
                 const int ro = (wm * 64 + i * 32 + fr) * XPITCH + kk + fk;
                 ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(&S[cur][0][0][ro]));
                 al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(&S[cur][0][1][ro]));
@@ -386,17 +449,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(GemmArgs g
     auto norm_strip = [&](float (&v)[16], bool kcontig, int mn_base, int mn_lim, int kb) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int mn = kcontig ? mn_base + (tid >> 1) : mn_base + (tid >> 5) * 16 + i;
-            const int k = kcontig ? kb + (tid & 1) * 16 + i : kb + (tid & 31);
+            const int mn = TNL ? mn_base + (tid & 31) * 4 + (i & 3) : kcontig ? mn_base + (tid >> 1) : mn_base + (tid >> 5) * 16 + i;
+            const int k = TNL ? kb + (tid >> 5) + 8 * (i >> 2) : kcontig ? kb + (tid & 1) * 16 + i : kb + (tid & 31);
             v[i] = (mn < mn_lim && k < kend) ? (v[i] - nsh) * nsc : 0.f;
         }
     };
-#define XLOAD(RA, RB, KB) do { xload_strip<!TA>(A, g.lda, m0, g.M, (KB), kend, tid, vecA, RA); \
-                               xload_strip<TB>(B, g.ldb, n0, g.N, (KB), kend, tid, vecB, RB); \
+#define XLOAD(RA, RB, KB) do { if constexpr (TNL) { tload_strip(A, g.lda, m0, g.M, (KB), kend, tid, vecA, RA); \
+                                                    tload_strip(B, g.ldb, n0, g.N, (KB), kend, tid, vecB, RB); } \
+                               else { xload_strip<!TA>(A, g.lda, m0, g.M, (KB), kend, tid, vecA, RA); \
+                                      xload_strip<TB>(B, g.ldb, n0, g.N, (KB), kend, tid, vecB, RB); } \
                                if (nrm == 1) norm_strip(RA, !TA, m0, g.M, (KB)); \
                                else if (nrm == 2) norm_strip(RB, TB, n0, g.N, (KB)); } while (0)
-#define XSTORE(RA, RB, BUF) do { xstore_strip<!TA>(S[BUF][0][0], S[BUF][0][1], tid, RA); \
-                                 xstore_strip<TB>(S[BUF][1][0], S[BUF][1][1], tid, RB); } while (0)
+#define XSTORE(RA, RB, BUF) do { if constexpr (TNL) { tstore_strip(S[BUF][0][0], S[BUF][0][1], tid, RA); \
+                                                      tstore_strip(S[BUF][1][0], S[BUF][1][1], tid, RB); } \
+                                 else { xstore_strip<!TA>(S[BUF][0][0], S[BUF][0][1], tid, RA); \
+                                        xstore_strip<TB>(S[BUF][1][0], S[BUF][1][1], tid, RB); } } while (0)
     if (kbeg < kend) {
         XLOAD(ra0, rb0, kbeg);
         XSTORE(ra0, rb0, 0);

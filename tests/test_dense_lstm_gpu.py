@@ -20,6 +20,7 @@ def rel_err(a, b):
 @pytest.mark.parametrize("tA,tB,M,N,K", [
     (0, 0, 128, 128, 16), (0, 1, 300, 200, 77), (1, 0, 129, 65, 40), (1, 1, 64, 257, 128),
     (0, 1, 1000, 29, 512), (0, 0, 500, 512, 29), (1, 0, 29, 512, 3000),
+    (1, 0, 260, 132, 100), (1, 0, 1024, 256, 4000),     # TN through the transposing-read LDS image (vector loads)
 ])
 @pytest.mark.parametrize("precision,tol", [(0, 1e-5), (1, 3e-5)])
 def test_gemm_layouts(tA, tB, M, N, K, precision, tol):
