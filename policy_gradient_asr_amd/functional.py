@@ -1,5 +1,7 @@
 """torch.autograd glue over the HIP kernels.  Activations are time-major (T,B,C).
 No function here has a CPU path: tensors must be on the MI355X."""
+import os
+
 import torch
 
 from . import hipops
@@ -38,6 +40,7 @@ class grad_overlap:
         return cls._sides[k]
 
     upper_grads_hook = None   # callable(swept_event): called by the FIRST layer's backward once every gradient above it is issued
+    tail_dx_first = os.environ.get("PGASR_TAIL_DX_FIRST", "1") != "0"
     split_tail = True  # no sweep follows the first layer's backward: run its dW_hh beside its dW_ih
     _sides2 = {}
 
@@ -315,7 +318,14 @@ class BLSTMLayerFn(torch.autograd.Function):
             side = grad_overlap.side_stream()
             tail = not ctx.sweep_follows
             hh_stream = grad_overlap.second_side_stream() if (tail and grad_overlap.split_tail) else None
-            grad_overlap.pending().append((swept, lambda: weight_grads(accumulate_into=targets, hh_stream=hh_stream)))
+            ready = swept
+            if tail and dx is not None and grad_overlap.tail_dx_first:
+                # no sweep is left to hide behind and the input gradient heads the only dependent chain of the tail
+                # (dropout/leaky', affine gradients, Adam): it gets the machine to itself, the weight-gradient GEMMs
+                # start when it is done and run beside that chain
+                ready = torch.cuda.Event()
+                ready.record()
+            grad_overlap.pending().append((ready, lambda: weight_grads(accumulate_into=targets, hh_stream=hh_stream)))
             if tail:
                 grad_overlap.flush()       # nothing left to hide behind: go now
             for t_ in (dg, x, out, dbias_part):
