@@ -320,16 +320,22 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 __device__ __forceinline__ void tload_strip(const float* __restrict__ P, int ld, int mn_base, int mn_lim,
                                             int k_base, int k_lim, int tid, bool vec_ok, float v[16]) {
     const int mn0 = mn_base + (tid & 31) * 4;
+    // interior tiles take a WORKGROUP-uniform branch (s_cbranch_scc, four back-to-back 16-byte loads); a per-lane
+    // condition here turns every load into its own exec-masked region
+    if (vec_ok && k_base + XBK <= k_lim && mn_base + BM <= mn_lim) {
+        const float* p = P + (size_t)(k_base + (tid >> 5)) * ld + mn0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 a = *reinterpret_cast<const float4*>(p + (size_t)(8 * i) * ld);
+            v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = k_base + (tid >> 5) + 8 * i;
-        if (k < k_lim && mn0 + 4 <= mn_lim && vec_ok) {
-            const float4 a = *reinterpret_cast<const float4*>(P + (size_t)k * ld + mn0);
-            v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w;
-        } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[4 * i + c] = (k < k_lim && mn0 + c < mn_lim) ? P[(size_t)k * ld + mn0 + c] : 0.f;
-        }
+        for (int c = 0; c < 4; ++c) v[4 * i + c] = (k < k_lim && mn0 + c < mn_lim) ? P[(size_t)k * ld + mn0 + c] : 0.f;
     }
 }
 
