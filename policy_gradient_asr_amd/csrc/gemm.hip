@@ -576,7 +576,32 @@ __global__ __launch_bounds__(1024) void instnorm_stats_kernel(const float* __res
     __shared__ double s1[16], s2[16];
     const float* p = x + (size_t)blockIdx.x * n_per;
     double a = 0.0, b = 0.0;
-    for (long long i = threadIdx.x; i < n_per; i += 1024) { const double v = p[i]; a += v; b += v * v; }
+    long long done = 0;
+    if (((n_per & 3) == 0) && ((((size_t)x) & 15) == 0)) {     // 16-byte loads, four in flight per thread
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        const long long n4 = n_per >> 2;
+        double a1 = 0.0, b1 = 0.0;
+        long long i = threadIdx.x;
+        for (; i + 3 * 1024 < n4; i += 4 * 1024) {
+            const float4 u0 = p4[i], u1 = p4[i + 1024], u2 = p4[i + 2 * 1024], u3 = p4[i + 3 * 1024];
+            a += ((double)u0.x + (double)u0.y) + ((double)u0.z + (double)u0.w);
+            b += ((double)u0.x * u0.x + (double)u0.y * u0.y) + ((double)u0.z * u0.z + (double)u0.w * u0.w);
+            a1 += ((double)u1.x + (double)u1.y) + ((double)u1.z + (double)u1.w);
+            b1 += ((double)u1.x * u1.x + (double)u1.y * u1.y) + ((double)u1.z * u1.z + (double)u1.w * u1.w);
+            a += ((double)u2.x + (double)u2.y) + ((double)u2.z + (double)u2.w);
+            b += ((double)u2.x * u2.x + (double)u2.y * u2.y) + ((double)u2.z * u2.z + (double)u2.w * u2.w);
+            a1 += ((double)u3.x + (double)u3.y) + ((double)u3.z + (double)u3.w);
+            b1 += ((double)u3.x * u3.x + (double)u3.y * u3.y) + ((double)u3.z * u3.z + (double)u3.w * u3.w);
+        }
+        for (; i < n4; i += 1024) {
+            const float4 u = p4[i];
+            a += ((double)u.x + (double)u.y) + ((double)u.z + (double)u.w);
+            b += ((double)u.x * u.x + (double)u.y * u.y) + ((double)u.z * u.z + (double)u.w * u.w);
+        }
+        a += a1; b += b1;
+        done = n_per;
+    }
+    for (long long i = done + threadIdx.x; i < n_per; i += 1024) { const double v = p[i]; a += v; b += v * v; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
     if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = a; s2[threadIdx.x >> 6] = b; }

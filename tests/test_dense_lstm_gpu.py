@@ -115,6 +115,21 @@ def test_instnorm_affine_fwd_bwd():
     assert rel_err(bg.grad.cpu(), bc.grad) < 1e-4
 
 
+@pytest.mark.parametrize("B,F,T", [(3, 80, 50), (2, 7, 33), (4, 80, 1000), (1, 120, 4099)])
+def test_instnorm_stats_vector_and_scalar_paths(B, F, T):
+    """mean / rstd over all F*T values of an utterance (model.py:37,48): 16-byte-load path (F*T % 4 == 0), the
+    scalar path, and a count that leaves a remainder after the four-deep unrolled loop."""
+    from policy_gradient_asr_amd import hipops
+    g = torch.Generator().manual_seed(B * F + T)
+    x = torch.randn(B, F, T, generator=g) * 2.5 - 0.7
+    mean, rstd = hipops.instnorm_stats(x.to(DEV), 1e-5)
+    xd = x.double().reshape(B, -1)
+    want_mean = xd.mean(dim=1)
+    want_rstd = 1.0 / torch.sqrt(xd.var(dim=1, unbiased=False) + 1e-5)
+    assert rel_err(mean.cpu(), want_mean) < 1e-6
+    assert rel_err(rstd.cpu(), want_rstd) < 1e-6
+
+
 def _lstm_case(T, B, lens, seed, in_dim=512):
     g = torch.Generator().manual_seed(seed)
     lstm = torch.nn.LSTM(in_dim, 256, 1, bidirectional=True)
