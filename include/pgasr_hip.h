@@ -175,6 +175,19 @@ int pgasr_split_bf16_planes(const float* src, int rows, int cols, int ld, int tr
 int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
                        const unsigned short* Wlo, float* C, int ldc, const float* bias,
                        const float* dact_y, float slope, void* stream);
+/* The same product FEEDING a forward LSTM sweep that is already running (csrc/gemm_dma.hip, FEED kernel): the input
+ * projection leaves the step's critical path.  Persistent workgroups on the XCDs the sweep leaves free draw
+ * 256 x 128 tiles in the order the sweep consumes rows (rows are (t, b) time-major; N = the two directions' column
+ * halves: row tile i of direction 0 together with row tile last-i of direction 1), store C write-through and count
+ * finished tiles in tiles_done[2][ceil(M/256)] (zeroed by the caller BEFORE the sweep is launched; a word is
+ * complete at N/256).  xcc_busy = the sweep's busy counters (pgasr_lstm_busy_offset): workgroups on a busy XCD
+ * take no tile, a second unmasked launch picks up any rest.  workspace >= 256 bytes.  Call order on the host:
+ * zero tiles_done -> pgasr_lstm_layer_fwd_fed (stream S) -> pgasr_stream_gate + this call (another stream that
+ * waits for the zeroing).  Needs N % 256 == 0 on top of pgasr_gemm_x3w_f32's conditions and M*ldc*4 < 2^31. */
+int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
+                            const unsigned short* Wlo, float* C, int ldc, const float* bias,
+                            const unsigned* xcc_busy, unsigned* tiles_done, void* workspace, size_t workspace_bytes,
+                            void* stream);
 
 size_t pgasr_colsum_workspace_bytes(int rows, int cols);
 int pgasr_colsum_f32(const float* X, int rows, int cols, int ld, float* out, float* out2, int accumulate,
@@ -237,6 +250,15 @@ int pgasr_stream_gate(const unsigned* words, int count, int timeout_us, void* st
 int pgasr_lstm_layer_fwd(float* gates, float* out, float* cbuf, const void* whh_pack_fwd,
                          const int32_t* lengths, int T, int B, int flags,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* pgasr_lstm_layer_fwd whose gates rows are produced WHILE it runs by pgasr_gemm_x3w_feed_f32 (launched after this
+ * call on another stream): fed = that call's tiles_done, fed_need = 8H/256 column tiles per direction.  The helper
+ * workgroups wait for a step's row tile(s) before they stage its rows and read them with agent-scope loads.
+ * PGASR_ERR_UNSUPPORTED when no XCD would be left for the GEMM (B > 32) or helpers are off (flags bit 2):
+ * pgasr_lstm_fed_ok(T, B, flags) != 0 says beforehand whether this call is possible. */
+int pgasr_lstm_layer_fwd_fed(float* gates, float* out, float* cbuf, const void* whh_pack_fwd,
+                             const int32_t* lengths, int T, int B, int flags, const unsigned* fed, int fed_need,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int pgasr_lstm_fed_ok(int T, int B, int flags);
 int pgasr_lstm_layer_bwd(float* gates, const float* out, const float* cbuf, const float* dout,
                          const void* whh_pack_bwd, const int32_t* lengths, int T, int B, int flags,
                          float* dbias_part, void* workspace, size_t workspace_bytes, void* stream);

@@ -43,6 +43,11 @@ struct DmaGemmArgs {
     const float* A; const unsigned short* Whi; const unsigned short* Wlo; float* C;
     int M, N, K, lda, ldc;
     const float* bias; const float* dact_y; float slope;
+    // feed-ahead mode (FEED kernels only): the consumer of C is a persistent LSTM sweep that is ALREADY RUNNING
+    unsigned* queue;            // tile counter (zeroed by the host)
+    const unsigned* xcc_busy;   // [8] per-XCD count of sweep clusters, or nullptr (sweeper pass: any XCD)
+    unsigned* tiles_done;       // [2][mt_count]: finished column tiles per (direction half of N, row tile)
+    int mt_count, nt_count;
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_base) {
@@ -107,14 +112,37 @@ __device__ __forceinline__ void split8(const u32x4_t& r0, const u32x4_t& r1, bf1
     hi = __builtin_bit_cast(bf16x8_t, h); lo = __builtin_bit_cast(bf16x8_t, l);
 }
 
+// FEED = the input projection runs BESIDE the forward sweep that consumes it (pgasr_gemm_x3w_feed_f32): persistent
+// workgroups on the XCDs the sweep leaves free draw tiles from a counter in the order the sweep needs them -- row
+// tile i of the forward direction's column half together with row tile (last - i) of the reverse direction's -- store
+// C write-through (sc1: the reader sits on another XCD, behind another L2) and count finished tiles per (direction,
+// row tile); the sweep's helper workgroups wait for that count before they stage a step's rows (lstm.hip).
+template <bool FEED>
 __global__ __launch_bounds__(DMA_THREADS) void gemm_x3w_kernel(DmaGemmArgs g) {
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];   // the ONLY LDS object
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
-    int tbx, tby;
-    swizzled_tile(tbx, tby);
-    const int m0 = tby * TM, n0 = tbx * TN;
     const int nk = g.K / TK;
+    if (FEED && g.xcc_busy) {       // a workgroup on one of the sweep's XCDs leaves at once (placement is read, not assumed)
+        const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;
+        if (__hip_atomic_load(g.xcc_busy + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    }
+  for (;;) {
+    int tbx, tby;
+    if (FEED) {
+        unsigned* mailbox = reinterpret_cast<unsigned*>(smem + NST * STAGE_BYTES);   // 16 bytes past the stages
+        if (tid == 0) *mailbox = __hip_atomic_fetch_add(g.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned t = *mailbox;
+        __syncthreads();
+        if (t >= (unsigned)g.mt_count * (unsigned)g.nt_count) return;
+        const int half = g.nt_count >> 1, grp = (int)(t / (unsigned)g.nt_count), j = (int)(t % (unsigned)g.nt_count);
+        tbx = j;
+        tby = j < half ? grp : g.mt_count - 1 - grp;
+    } else {
+        swizzled_tile(tbx, tby);
+    }
+    const int m0 = tby * TM, n0 = tbx * TN;
 
     // ---- per-lane DMA sources (k offset added per tile) ----
     const float* pa[4];
@@ -204,6 +232,8 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_x3w_kernel(DmaGemmArgs g) {
 
     // epilogue: 32x32 accumulator layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int cl = lane & 31, rq = lane >> 5;
+    __amdgpu_buffer_rsrc_t crs;
+    if (FEED) crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)((size_t)g.M * g.ldc * 4), 0x00020000);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -216,9 +246,18 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_x3w_kernel(DmaGemmArgs g) {
                 if (m >= g.M) continue;
                 float v = acc[i][j][r] + bsum;
                 if (g.dact_y) v *= (g.dact_y[(size_t)m * g.ldc + n] > 0.f ? 1.f : g.slope);
-                g.C[(size_t)m * g.ldc + n] = v;
+                if (FEED) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crs, (unsigned)(((size_t)m * g.ldc + n) * 4), 0, 16);
+                else g.C[(size_t)m * g.ldc + n] = v;
             }
         }
+    if (!FEED) return;
+    // the tile's stores have reached memory (vmcnt(0) in every wave, then the barrier) before it is counted; the
+    // barrier also retires every DMA of this tile before the next one reuses the stages
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        __hip_atomic_fetch_add(g.tiles_done + (tbx < (g.nt_count >> 1) ? 0 : g.mt_count) + tby, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // fp32 (rows x cols, leading dim ld) -> dense bf16 hi / lo planes; transpose: planes are (cols x rows)
@@ -257,10 +296,42 @@ extern "C" int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, 
     const unsigned gy = (unsigned)((M + TM - 1) / TM);
     if (gy > 65535u) return PGASR_ERR_UNSUPPORTED;
     const size_t lds = (size_t)NST * STAGE_BYTES;   // 144 KB of the CU's 160 KB: opt in per call (idempotent, no state kept)
-    if (hipFuncSetAttribute((const void*)gemm_x3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_x3w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
-    DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, dact_y, slope};
-    PGASR_LAUNCH_KERNEL(gemm_x3w_kernel, dim3((unsigned)(N / TN), gy), dim3(DMA_THREADS), lds, (hipStream_t)stream, g);
+    DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, dact_y, slope, nullptr, nullptr, nullptr, 0, 0};
+    PGASR_LAUNCH_KERNEL(gemm_x3w_kernel<false>, dim3((unsigned)(N / TN), gy), dim3(DMA_THREADS), lds, (hipStream_t)stream, g);
     PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
+
+// The same product in feed-ahead mode (see the FEED kernel): C rows are produced in the order a forward LSTM sweep
+// that is already running consumes them (N = the two directions' column halves, rows = (t, b) time-major).
+//   tiles_done : [2][ceil(M/256)] words, zeroed by the caller BEFORE the sweep is launched; word [d][i] reaches N/256
+//                when rows [256 i, 256 i + 256) of direction d's columns are in memory
+//   xcc_busy   : the sweep's per-XCD busy counters (pgasr_lstm_busy_offset); workgroups that find themselves on a
+//                busy XCD take no tile; a second, unmasked launch picks up whatever is left (normally nothing)
+//   workspace  : >= 256 bytes (tile counter)
+extern "C" int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
+                                       const unsigned short* Wlo, float* C, int ldc, const float* bias,
+                                       const unsigned* xcc_busy, unsigned* tiles_done, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    if (!A || !Whi || !Wlo || !C || !tiles_done || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N) return PGASR_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < 256) return PGASR_ERR_WORKSPACE;
+    if ((K % TK) || (N % (2 * TN)) || (lda & 3) || (((size_t)A) & 15) || (((size_t)Whi) & 15) || (((size_t)Wlo) & 15))
+        return PGASR_ERR_UNSUPPORTED;
+    if ((size_t)M * ldc * 4 >= ((size_t)1 << 31)) return PGASR_ERR_UNSUPPORTED;      // buffer-addressed stores
+    const int mt = (M + TM - 1) / TM, nt = N / TN;
+    const size_t lds = (size_t)NST * STAGE_BYTES + 16;
+    if (hipFuncSetAttribute((const void*)gemm_x3w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PGASR_ERR_LAUNCH;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, 256, st) != hipSuccess) return PGASR_ERR_LAUNCH;
+    DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, nullptr, 0.f, (unsigned*)workspace, xcc_busy, tiles_done, mt, nt};
+    // one persistent workgroup per CU (144 KB of LDS each); pass 1 ignores the busy counters
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) g.xcc_busy = nullptr;
+        PGASR_LAUNCH_KERNEL(gemm_x3w_kernel<true>, dim3(256), dim3(DMA_THREADS), lds, st, g);
+        PGASR_CHECK_LAUNCH();
+    }
     return PGASR_OK;
 }

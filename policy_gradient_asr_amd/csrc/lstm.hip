@@ -83,6 +83,8 @@ struct LstmArgs {
     float* ring;             // [clusters][RING_STEPS][step floats]: the rows of the next steps, staged by the helper workgroups
     unsigned* ready;         // [clusters][32]: word i = (step + 1) held by ring slot i (0 = nothing yet), zeroed per call
     int n_helpers;           // helper workgroups per cluster: N_HELPERS, or 0 when two clusters must share an XCD (B > 64)
+    const unsigned* fed;     // (forward, optional) [2][fed_mt] finished-tile counts of an input projection that runs BESIDE this sweep
+    int fed_mt, fed_need;    // row tiles of 256 (t, b) rows; a row tile is complete at fed_need (gemm_dma.hip, FEED kernel)
     int* err;                // set to 1 when a bounded wait gives up
     unsigned* busy;          // [8] per-XCD count of clusters currently sweeping there (read by queue-mode GEMMs)
     const int* lengths;      // [B]
@@ -236,10 +238,33 @@ __device__ __forceinline__ void helper_loop(const LstmArgs& a, int cl, int dir, 
         const int t = backward ? (dir ? s : T - 1 - s) : (dir ? T - 1 - s : s);
         const unsigned slot_off = (unsigned)((s % RING_STEPS) * step_floats);
         u32x4 v[16];
+        if (!backward && a.fed) {
+            // the projection GEMM is still running (on other XCDs): wait until the row tile(s) holding this step's 16
+            // rows are counted complete, then read them with agent-scope loads (they were written through to memory)
+            const int blast = bg * 16 + 15 < B ? bg * 16 + 15 : B - 1;
+            const int mt0 = (t * B + bg * 16) >> 8, mt1 = (t * B + blast) >> 8;
+            while (true) {
+                POLL_FENCE();
+                const unsigned c0 = __hip_atomic_load(a.fed + dir * a.fed_mt + mt0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned c1 = __hip_atomic_load(a.fed + dir * a.fed_mt + mt1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c0 >= (unsigned)a.fed_need && c1 >= (unsigned)a.fed_need) break;
+                __builtin_amdgcn_s_sleep(4);
+                if (!sg.keep_waiting()) { *a.err = 1; return; }
+            }
+            sg.spins = 0;
+            POLL_FENCE();
+            __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(a.gates, 0, (int)((size_t)T * B * 2 * HID * 4 * 4), 0x00020000);
 #pragma unroll
-        for (int n = 0; n < 16; ++n) {
-            int b = bg * 16 + n; b = b < B ? b : B - 1;
-            v[n] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.gates + ((((size_t)t * B + b) * 2 + dir) * HID) * 4 + w * 256 + lane * 4));   // streamed once: should not displace the ring in L2
+            for (int n = 0; n < 16; ++n) {
+                int b = bg * 16 + n; b = b < B ? b : B - 1;
+                v[n] = __builtin_amdgcn_raw_buffer_load_b128(grs, (unsigned)((((((size_t)t * B + b) * 2 + dir) * HID) * 4 + w * 256 + lane * 4) * 4), 0, 16);
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                int b = bg * 16 + n; b = b < B ? b : B - 1;
+                v[n] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.gates + ((((size_t)t * B + b) * 2 + dir) * HID) * 4 + w * 256 + lane * 4));   // streamed once: should not displace the ring in L2
+            }
         }
         u32x4 vc[4], vd[4];
         if (backward) {
@@ -962,7 +987,8 @@ extern "C" size_t pgasr_lstm_workspace_bytes(int T, int B, int backward) {
 }
 
 static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, const float* dout, float* dbias_part, const void* wpack,
-                       const int* lengths, int T, int B, int flags, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                       const int* lengths, int T, int B, int flags, void* workspace, size_t workspace_bytes, hipStream_t st,
+                       const unsigned* fed = nullptr, int fed_need = 0) {
     if (!gates || !out || !cbuf || !wpack || !lengths || T <= 0 || B <= 0) return PGASR_ERR_INVALID_ARG;
     if (backward && !dout) return PGASR_ERR_INVALID_ARG;
     const WsLayout l = lstm_ws_layout(B, backward);
@@ -992,6 +1018,12 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
     // extra workgroups onto an XCD that already holds a cluster (measured: B = 80 deadlocked until the time-outs
     // with 2 x 20 workgroups on one XCD): with more than 8 clusters the loaders read HBM themselves, as before.
     a.n_helpers = (2 * l.NBG <= 8 && !(flags & 4)) ? N_HELPERS : 0;      // flags bit 2: no helpers (two processes sharing one GPU)
+    a.fed = fed; a.fed_mt = (int)(((size_t)T * B + 255) / 256); a.fed_need = fed_need;
+    if (fed) {
+        // a fed sweep waits for a GEMM that must find XCDs of its own: helpers on, at most 4 clusters (half the chip)
+        if (backward || fed_need <= 0 || a.n_helpers == 0 || 2 * l.NBG > 4) return PGASR_ERR_UNSUPPORTED;
+        if ((size_t)T * B * 2 * HID * 4 * 4 >= ((size_t)1 << 31)) return PGASR_ERR_UNSUPPORTED;     // buffer-addressed loads
+    }
     dim3 grid((G_CLUSTER + a.n_helpers) * l.NCL8);   // + the helper workgroups of each cluster
     if (backward) PGASR_LAUNCH_KERNEL(lstm_bwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
     else PGASR_LAUNCH_KERNEL(lstm_fwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
@@ -1004,6 +1036,27 @@ extern "C" int pgasr_lstm_layer_fwd(float* gates, float* out, float* cbuf, const
                                     void* workspace, size_t workspace_bytes, void* stream) {
     return lstm_launch(false, gates, out, cbuf, nullptr, nullptr, whh_pack_fwd, lengths, T, B, flags, workspace, workspace_bytes,
                        (hipStream_t)stream);
+}
+
+// Forward sweep whose input projection is produced WHILE it runs (pgasr_gemm_x3w_feed_f32 on another stream, launched
+// after this call): ``fed`` = that call's tiles_done words (zeroed by the caller before this launch), ``fed_need`` =
+// column tiles per direction (8H / 256).  PGASR_ERR_UNSUPPORTED when the sweep cannot be fed (more than 32
+// utterances: no XCD would be left for the GEMM; helpers disabled): run the projection first and call
+// pgasr_lstm_layer_fwd instead.  pgasr_lstm_fed_ok answers the same question without launching.
+extern "C" int pgasr_lstm_layer_fwd_fed(float* gates, float* out, float* cbuf, const void* whh_pack_fwd,
+                                        const int32_t* lengths, int T, int B, int flags, const unsigned* fed, int fed_need,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (!fed) return PGASR_ERR_INVALID_ARG;
+    return lstm_launch(false, gates, out, cbuf, nullptr, nullptr, whh_pack_fwd, lengths, T, B, flags, workspace, workspace_bytes,
+                       (hipStream_t)stream, fed, fed_need);
+}
+
+extern "C" int pgasr_lstm_fed_ok(int T, int B, int flags) {
+    if (T <= 0 || B <= 0) return 0;
+    const WsLayout l = lstm_ws_layout(B, false);
+    if (2 * l.NBG > 4 || (flags & 4)) return 0;
+    if ((size_t)T * B * 2 * HID * 4 * 4 >= ((size_t)1 << 31)) return 0;
+    return 1;
 }
 
 extern "C" int pgasr_lstm_layer_bwd(float* gates, const float* out, const float* cbuf, const float* dout,

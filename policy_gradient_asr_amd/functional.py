@@ -7,6 +7,7 @@ import torch
 from . import hipops
 
 HID = hipops.HID
+FEED_AHEAD = os.environ.get("PGASR_FEED_AHEAD", "1") != "0"   # input projections run beside the forward sweeps they feed
 LEAKY_SLOPE = 0.01   # F.leaky_relu default, model.py:50
 
 
@@ -230,13 +231,32 @@ class BLSTMLayerFn(torch.autograd.Function):
         ctx.planes_t = prepacked.planes_t
         G = 2 * 4 * HID
         gates = torch.empty(T, B, G, dtype=torch.float32, device=x.device)
-        if prepacked.planes is not None and hipops.gemm_x3w_ok(T * B, G, I):   # LDS-DMA kernel, pre-split weight planes
-            hipops.gemm_x3w(x, prepacked.planes, gates, T * B, G, I, bias=bias_perm)
-        else:
-            hipops.gemm(x, wih_perm, gates, M=T * B, N=G, K=I, transB=True, bias=bias_perm)
         out = torch.empty(T, B, 2 * HID, dtype=torch.float32, device=x.device)
         cbuf = torch.empty(T, B, 2 * HID, dtype=torch.float32, device=x.device)
-        hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B)
+        x3w = prepacked.planes is not None and hipops.gemm_x3w_ok(T * B, G, I)   # LDS-DMA kernel, pre-split weight planes
+        if x3w and FEED_AHEAD and hipops.lstm_fed_ok(T, B):
+            # the projection leaves the critical path: the sweep is launched FIRST and its helper workgroups wait for
+            # the row tiles a GEMM on the side stream produces, in consumption order, on the XCDs the sweep leaves free
+            main = torch.cuda.current_stream()
+            side = grad_overlap.side_stream()
+            done = torch.zeros(2 * ((T * B + 255) // 256), dtype=torch.int32, device=x.device)
+            zeroed = torch.cuda.Event()
+            zeroed.record()
+            hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, fed=done, fed_need=G // 256)
+            side.wait_event(zeroed)
+            busy = hipops.lstm_busy_ptr(T, B, False, x.device)
+            with torch.cuda.stream(side):
+                hipops.stream_gate(busy)
+                hipops.gemm_x3w_feed(x, prepacked.planes, gates, T * B, G, I, bias_perm, busy, done)
+            for t_ in (x, gates, done, bias_perm) + tuple(prepacked.planes):
+                t_.record_stream(side)
+            main.wait_stream(side)
+        else:
+            if x3w:
+                hipops.gemm_x3w(x, prepacked.planes, gates, T * B, G, I, bias=bias_perm)
+            else:
+                hipops.gemm(x, wih_perm, gates, M=T * B, N=G, K=I, transB=True, bias=bias_perm)
+            hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B)
         ctx.save_for_backward(x, lengths, gates, out, cbuf, wih_perm, pack_b, dact_y if dact_y is not None else x.new_empty(0))
         ctx.has_dact = dact_y is not None
         ctx.sweep_follows = bool(sweep_follows)   # backward: another layer's sweep runs right after this one

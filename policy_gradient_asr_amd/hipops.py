@@ -365,13 +365,44 @@ def _lstm_ws(T, B, backward, device):
 LSTM_FLAGS = 0   # bit 0: force the write-through (cross-XCD) hand-off protocol
 
 
-def lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B):
+def lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, fed=None, fed_need=0):
+    """fed: int32 (2, ceil(T*B/256)) finished-tile counters of a ``gemm_x3w_feed`` that is launched AFTER this call on
+    another stream and fills ``gates`` while the sweep runs (zeroed by the caller before this call)."""
     lib = _lib.load()
     ws = _lstm_ws(T, B, False, gates.device)
     with _timed("lstm_fwd_kernel"):
-        st = lib.pgasr_lstm_layer_fwd(_p(gates), _p(out), _p(cbuf), _p(pack_f), _p(lengths), T, B, LSTM_FLAGS, _p(ws), ws.numel(), _stream())
-    _lib.check(st, "pgasr_lstm_layer_fwd")
+        if fed is None:
+            st = lib.pgasr_lstm_layer_fwd(_p(gates), _p(out), _p(cbuf), _p(pack_f), _p(lengths), T, B, LSTM_FLAGS, _p(ws), ws.numel(), _stream())
+        else:
+            if fed.dtype != torch.int32 or not fed.is_cuda or fed.numel() < 2 * ((T * B + 255) // 256):
+                raise _lib.PgasrError("lstm_layer_fwd: fed must be an int32 GPU tensor of 2 * ceil(T*B/256) words")
+            st = lib.pgasr_lstm_layer_fwd_fed(_p(gates), _p(out), _p(cbuf), _p(pack_f), _p(lengths), T, B, LSTM_FLAGS,
+                                              _p(fed), int(fed_need), _p(ws), ws.numel(), _stream())
+    _lib.check(st, "pgasr_lstm_layer_fwd_fed" if fed is not None else "pgasr_lstm_layer_fwd")
     return ws
+
+
+def lstm_fed_ok(T, B):
+    """Can a forward sweep of this shape be fed by a concurrent projection GEMM (B <= 32, helpers on)?"""
+    return bool(_lib.load().pgasr_lstm_fed_ok(T, B, LSTM_FLAGS))
+
+
+def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done):
+    """``gemm_x3w`` in feed-ahead mode on the CURRENT stream (see include/pgasr_hip.h, pgasr_gemm_x3w_feed_f32)."""
+    lib = _lib.load()
+    hi, lo = planes
+    for t, nm in ((A, "A"), (C, "C"), (bias, "bias")):
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32):
+            raise _lib.PgasrError(f"gemm_x3w_feed operand {nm} must be a float32 GPU tensor")
+    if tuple(hi.shape) != (N, K) or tuple(lo.shape) != (N, K) or hi.dtype != torch.int16 or not hi.is_contiguous() or not lo.is_contiguous():
+        raise _lib.PgasrError("gemm_x3w_feed planes must be contiguous int16 (N, K)")
+    if tiles_done.dtype != torch.int32 or tiles_done.numel() < 2 * ((M + 255) // 256):
+        raise _lib.PgasrError("gemm_x3w_feed: tiles_done must hold 2 * ceil(M/256) int32 words")
+    ws = _workspace(256, C.device, "x3w_feed")
+    st = lib.pgasr_gemm_x3w_feed_f32(M, N, K, A.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), C.data_ptr(), N, _p(bias),
+                                     busy_ptr, tiles_done.data_ptr(), _p(ws), ws.numel(), _stream())
+    _lib.check(st, "pgasr_gemm_x3w_feed_f32")
+    return C
 
 
 def lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=False):

@@ -197,6 +197,39 @@ def test_blstm_write_through_protocol_matches_default():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("T,B,lens", [
+    (200, 32, [200] * 32),                          # 8 time steps per 256-row tile: the headline geometry
+    (61, 20, [61] * 7 + list(range(60, 47, -1))),   # steps straddle row tiles, ragged last tile, second group of 4
+    (1, 3, [1] * 3), (9, 16, [9] * 16),
+])
+def test_blstm_fed_by_concurrent_projection_matches_sequential(T, B, lens):
+    """The forward sweep fed by a projection GEMM that runs beside it (functional.FEED_AHEAD: sweep launched first,
+    helper workgroups wait per row tile) gives bit-identical outputs, saved activations and gradients to the
+    projection-then-sweep order; B > 32 falls back to the sequential order by itself."""
+    from policy_gradient_asr_amd import functional as Fh, hipops
+    assert hipops.lstm_fed_ok(T, B) and not hipops.lstm_fed_ok(T, 33)
+    lstm, x, dy, lengths = _lstm_case(T, B, lens, seed=7 + T)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0",
+             "weight_ih_l0_reverse", "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+    res = []
+    prev = Fh.FEED_AHEAD
+    try:
+        for feed in (False, True, True):
+            Fh.FEED_AHEAD = feed
+            params = [getattr(lstm, n).detach().to(DEV).requires_grad_(True) for n in names]
+            xg = x.to(DEV).requires_grad_(True)
+            y = Fh.blstm_layer(xg, lengths.to(torch.int32).to(DEV), params)
+            y.backward(dy.to(DEV))
+            torch.cuda.synchronize()
+            hipops.lstm_check_error(hipops._lstm_ws(T, B, False, xg.device), B, False)
+            res.append([y.detach().cpu(), xg.grad.cpu()] + [p.grad.cpu() for p in params])
+    finally:
+        Fh.FEED_AHEAD = prev
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
+
+
 def test_encoder_matches_reference_golden(golden_dir):
     """Encoder on the MI355X vs the reference model.Encoder outputs (tests/golden)."""
     from policy_gradient_asr_amd.model import Encoder
