@@ -183,11 +183,12 @@ int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, const unsig
  * complete at N/256).  xcc_busy = the sweep's busy counters (pgasr_lstm_busy_offset): workgroups on a busy XCD
  * take no tile, a second unmasked launch picks up any rest.  workspace >= 256 bytes.  Call order on the host:
  * zero tiles_done -> pgasr_lstm_layer_fwd_fed (stream S) -> pgasr_stream_gate + this call (another stream that
- * waits for the zeroing).  Needs N % 256 == 0 on top of pgasr_gemm_x3w_f32's conditions and M*ldc*4 < 2^31. */
+ * waits for the zeroing).  order 0: rows in the order a forward sweep consumes them; 1: a backward sweep's (the
+ * product is then the input gradient of the layer above, feeding pgasr_lstm_layer_bwd_fed).  Needs N % 256 == 0 on top of pgasr_gemm_x3w_f32's conditions and M*ldc*4 < 2^31. */
 int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
                             const unsigned short* Wlo, float* C, int ldc, const float* bias,
-                            const unsigned* xcc_busy, unsigned* tiles_done, void* workspace, size_t workspace_bytes,
-                            void* stream);
+                            const unsigned* xcc_busy, unsigned* tiles_done, int order, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 size_t pgasr_colsum_workspace_bytes(int rows, int cols);
 int pgasr_colsum_f32(const float* X, int rows, int cols, int ld, float* out, float* out2, int accumulate,
@@ -259,6 +260,14 @@ int pgasr_lstm_layer_fwd_fed(float* gates, float* out, float* cbuf, const void* 
                              const int32_t* lengths, int T, int B, int flags, const unsigned* fed, int fed_need,
                              void* workspace, size_t workspace_bytes, void* stream);
 int pgasr_lstm_fed_ok(int T, int B, int flags);
+/* Backward counterpart: dout (= the input gradient of the layer above) is produced while the sweep runs by
+ * pgasr_gemm_x3w_feed_f32(order = 1); fed_need = 2H/256.  drop_p != 0: dout arrives WITHOUT the inter-layer dropout
+ * mask (model.py:42) and the helper workgroups apply pgasr_dropout(drop_p, drop_seed, drop_offset)'s mask to the rows
+ * they stage -- the separate dropout pass between the layers disappears. */
+int pgasr_lstm_layer_bwd_fed(float* gates, const float* out, const float* cbuf, const float* dout,
+                             const void* whh_pack_bwd, const int32_t* lengths, int T, int B, int flags,
+                             float* dbias_part, const unsigned* fed, int fed_need, float drop_p, uint64_t drop_seed,
+                             uint32_t drop_offset, void* workspace, size_t workspace_bytes, void* stream);
 int pgasr_lstm_layer_bwd(float* gates, const float* out, const float* cbuf, const float* dout,
                          const void* whh_pack_bwd, const int32_t* lengths, int T, int B, int flags,
                          float* dbias_part, void* workspace, size_t workspace_bytes, void* stream);

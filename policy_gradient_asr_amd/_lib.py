@@ -54,7 +54,7 @@ SIGNATURES = {
     "pgasr_gemm_x3w_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_ptr, c_ptr, c_f32p, C.c_int,
                                      c_f32p, c_f32p, C.c_float, c_ptr]),
     "pgasr_gemm_x3w_feed_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_ptr, c_ptr, c_f32p, C.c_int,
-                                          c_f32p, c_ptr, c_ptr, c_ptr, C.c_size_t, c_ptr]),
+                                          c_f32p, c_ptr, c_ptr, C.c_int, c_ptr, C.c_size_t, c_ptr]),
     "pgasr_feat_frames": (C.c_int, [c_f32p, c_i32p, c_i32p, C.c_int, C.c_longlong, C.c_int, c_f32p, c_ptr]),
     "pgasr_feat_power": (C.c_int, [c_f32p, C.c_longlong, c_f32p, c_ptr]),
     "pgasr_feat_db": (C.c_int, [c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_float, c_ptr]),
@@ -76,6 +76,8 @@ SIGNATURES = {
     "pgasr_lstm_layer_fwd_fed": (C.c_int, [c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int, c_ptr, C.c_int,
                                            c_ptr, C.c_size_t, c_ptr]),
     "pgasr_lstm_fed_ok": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "pgasr_lstm_layer_bwd_fed": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int,
+                                           c_f32p, c_ptr, C.c_int, C.c_float, C.c_uint64, C.c_uint32, c_ptr, C.c_size_t, c_ptr]),
     "pgasr_lstm_layer_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int,
                                        c_f32p, c_ptr, C.c_size_t, c_ptr]),
 }

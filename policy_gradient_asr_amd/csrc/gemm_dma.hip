@@ -47,7 +47,7 @@ struct DmaGemmArgs {
     unsigned* queue;            // tile counter (zeroed by the host)
     const unsigned* xcc_busy;   // [8] per-XCD count of sweep clusters, or nullptr (sweeper pass: any XCD)
     unsigned* tiles_done;       // [2][mt_count]: finished column tiles per (direction half of N, row tile)
-    int mt_count, nt_count;
+    int mt_count, nt_count, order;   // order 0: forward-sweep consumption order, 1: backward-sweep order (mirrored)
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_base) {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_x3w_kernel(DmaGemmArgs g) {
         if (t >= (unsigned)g.mt_count * (unsigned)g.nt_count) return;
         const int half = g.nt_count >> 1, grp = (int)(t / (unsigned)g.nt_count), j = (int)(t % (unsigned)g.nt_count);
         tbx = j;
-        tby = j < half ? grp : g.mt_count - 1 - grp;
+        tby = ((j < half) != (g.order != 0)) ? grp : g.mt_count - 1 - grp;
     } else {
         swizzled_tile(tbx, tby);
     }
@@ -298,7 +298,7 @@ extern "C" int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, 
     const size_t lds = (size_t)NST * STAGE_BYTES;   // 144 KB of the CU's 160 KB: opt in per call (idempotent, no state kept)
     if (hipFuncSetAttribute((const void*)gemm_x3w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
-    DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, dact_y, slope, nullptr, nullptr, nullptr, 0, 0};
+    DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, dact_y, slope, nullptr, nullptr, nullptr, 0, 0, 0};
     PGASR_LAUNCH_KERNEL(gemm_x3w_kernel<false>, dim3((unsigned)(N / TN), gy), dim3(DMA_THREADS), lds, (hipStream_t)stream, g);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
@@ -310,12 +310,15 @@ extern "C" int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, 
 //                when rows [256 i, 256 i + 256) of direction d's columns are in memory
 //   xcc_busy   : the sweep's per-XCD busy counters (pgasr_lstm_busy_offset); workgroups that find themselves on a
 //                busy XCD take no tile; a second, unmasked launch picks up whatever is left (normally nothing)
+//   order      : 0 = rows in the order a FORWARD sweep consumes them (direction 0 ascending in t, direction 1
+//                descending), 1 = the order of a BACKWARD sweep (mirrored)
 //   workspace  : >= 256 bytes (tile counter)
 extern "C" int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
                                        const unsigned short* Wlo, float* C, int ldc, const float* bias,
-                                       const unsigned* xcc_busy, unsigned* tiles_done, void* workspace,
+                                       const unsigned* xcc_busy, unsigned* tiles_done, int order, void* workspace,
                                        size_t workspace_bytes, void* stream) {
     if (!A || !Whi || !Wlo || !C || !tiles_done || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N) return PGASR_ERR_INVALID_ARG;
+    if (order < 0 || order > 1) return PGASR_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < 256) return PGASR_ERR_WORKSPACE;
     if ((K % TK) || (N % (2 * TN)) || (lda & 3) || (((size_t)A) & 15) || (((size_t)Whi) & 15) || (((size_t)Wlo) & 15))
         return PGASR_ERR_UNSUPPORTED;
@@ -326,7 +329,7 @@ extern "C" int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int 
         return PGASR_ERR_LAUNCH;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(workspace, 0, 256, st) != hipSuccess) return PGASR_ERR_LAUNCH;
-    DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, nullptr, 0.f, (unsigned*)workspace, xcc_busy, tiles_done, mt, nt};
+    DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, nullptr, 0.f, (unsigned*)workspace, xcc_busy, tiles_done, mt, nt, order};
     // one persistent workgroup per CU (144 KB of LDS each); pass 1 ignores the busy counters
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) g.xcc_busy = nullptr;

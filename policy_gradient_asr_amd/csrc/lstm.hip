@@ -85,6 +85,9 @@ struct LstmArgs {
     int n_helpers;           // helper workgroups per cluster: N_HELPERS, or 0 when two clusters must share an XCD (B > 64)
     const unsigned* fed;     // (forward, optional) [2][fed_mt] finished-tile counts of an input projection that runs BESIDE this sweep
     int fed_mt, fed_need;    // row tiles of 256 (t, b) rows; a row tile is complete at fed_need (gemm_dma.hip, FEED kernel)
+                             // backward: the fed tensor is dout = the input gradient of the layer above, optionally still
+                             // WITHOUT the inter-layer dropout mask, which the helpers then apply while they stage its rows
+    unsigned drop_thresh, drop_k0, drop_k1, drop_off; float drop_scale; int drop_on;
     int* err;                // set to 1 when a bounded wait gives up
     unsigned* busy;          // [8] per-XCD count of clusters currently sweeping there (read by queue-mode GEMMs)
     const int* lengths;      // [B]
@@ -238,9 +241,11 @@ __device__ __forceinline__ void helper_loop(const LstmArgs& a, int cl, int dir, 
         const int t = backward ? (dir ? s : T - 1 - s) : (dir ? T - 1 - s : s);
         const unsigned slot_off = (unsigned)((s % RING_STEPS) * step_floats);
         u32x4 v[16];
-        if (!backward && a.fed) {
-            // the projection GEMM is still running (on other XCDs): wait until the row tile(s) holding this step's 16
-            // rows are counted complete, then read them with agent-scope loads (they were written through to memory)
+        if (a.fed) {
+            // the GEMM that produces this sweep's rows (forward: the input projection into gates; backward: the input
+            // gradient of the layer above into dout) is still running on other XCDs: wait until the row tile(s) holding
+            // this step's 16 rows are counted complete; the rows are then read with agent-scope loads (they were
+            // written through to memory)
             const int blast = bg * 16 + 15 < B ? bg * 16 + 15 : B - 1;
             const int mt0 = (t * B + bg * 16) >> 8, mt1 = (t * B + blast) >> 8;
             while (true) {
@@ -253,6 +258,8 @@ __device__ __forceinline__ void helper_loop(const LstmArgs& a, int cl, int dir, 
             }
             sg.spins = 0;
             POLL_FENCE();
+        }
+        if (!backward && a.fed) {
             __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(a.gates, 0, (int)((size_t)T * B * 2 * HID * 4 * 4), 0x00020000);
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
@@ -273,7 +280,36 @@ __device__ __forceinline__ void helper_loop(const LstmArgs& a, int cl, int dir, 
                 const int i = j * 256 + tid;                  // 16-byte chunk of the 16 x 256 floats
                 int b = bg * 16 + (i >> 6); b = b < B ? b : B - 1;
                 vc[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.cbuf + (((size_t)t * B + b) * 2 + dir) * HID + (i & 63) * 4));
-                vd[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.dout + ((size_t)t * B + b) * (2 * HID) + dir * HID + (i & 63) * 4));
+            }
+            if (a.fed) {
+                __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dout), 0, (int)((size_t)T * B * 2 * HID * 4), 0x00020000);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = j * 256 + tid;
+                    int b = bg * 16 + (i >> 6); b = b < B ? b : B - 1;
+                    vd[j] = __builtin_amdgcn_raw_buffer_load_b128(drs, (unsigned)((((size_t)t * B + b) * (2 * HID) + dir * HID + (i & 63) * 4) * 4), 0, 16);
+                }
+                if (a.drop_on) {      // nn.LSTM's inter-layer dropout (model.py:42), same mask as pgasr_dropout: one Philox call per 4 elements
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = j * 256 + tid;
+                        int b = bg * 16 + (i >> 6); b = b < B ? b : B - 1;
+                        const unsigned long long quad = (((unsigned long long)t * B + b) * (2 * HID) + dir * HID + (i & 63) * 4) >> 2;
+                        uint32_t r[4];
+                        philox4x32_10((uint32_t)quad, (uint32_t)(quad >> 32), a.drop_off, 0u, a.drop_k0, a.drop_k1, r);
+                        vd[j].x = r[0] >= a.drop_thresh ? __float_as_uint(__uint_as_float(vd[j].x) * a.drop_scale) : 0u;
+                        vd[j].y = r[1] >= a.drop_thresh ? __float_as_uint(__uint_as_float(vd[j].y) * a.drop_scale) : 0u;
+                        vd[j].z = r[2] >= a.drop_thresh ? __float_as_uint(__uint_as_float(vd[j].z) * a.drop_scale) : 0u;
+                        vd[j].w = r[3] >= a.drop_thresh ? __float_as_uint(__uint_as_float(vd[j].w) * a.drop_scale) : 0u;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = j * 256 + tid;
+                    int b = bg * 16 + (i >> 6); b = b < B ? b : B - 1;
+                    vd[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.dout + ((size_t)t * B + b) * (2 * HID) + dir * HID + (i & 63) * 4));
+                }
             }
         }
         const int aux = same ? 0 : 16;
@@ -988,7 +1024,8 @@ extern "C" size_t pgasr_lstm_workspace_bytes(int T, int B, int backward) {
 
 static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, const float* dout, float* dbias_part, const void* wpack,
                        const int* lengths, int T, int B, int flags, void* workspace, size_t workspace_bytes, hipStream_t st,
-                       const unsigned* fed = nullptr, int fed_need = 0) {
+                       const unsigned* fed = nullptr, int fed_need = 0, float drop_p = 0.f, uint64_t drop_seed = 0,
+                       uint32_t drop_offset = 0) {
     if (!gates || !out || !cbuf || !wpack || !lengths || T <= 0 || B <= 0) return PGASR_ERR_INVALID_ARG;
     if (backward && !dout) return PGASR_ERR_INVALID_ARG;
     const WsLayout l = lstm_ws_layout(B, backward);
@@ -1021,8 +1058,16 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
     a.fed = fed; a.fed_mt = (int)(((size_t)T * B + 255) / 256); a.fed_need = fed_need;
     if (fed) {
         // a fed sweep waits for a GEMM that must find XCDs of its own: helpers on, at most 4 clusters (half the chip)
-        if (backward || fed_need <= 0 || a.n_helpers == 0 || 2 * l.NBG > 4) return PGASR_ERR_UNSUPPORTED;
+        if (fed_need <= 0 || a.n_helpers == 0 || 2 * l.NBG > 4) return PGASR_ERR_UNSUPPORTED;
         if ((size_t)T * B * 2 * HID * 4 * 4 >= ((size_t)1 << 31)) return PGASR_ERR_UNSUPPORTED;     // buffer-addressed loads
+    }
+    a.drop_on = 0; a.drop_thresh = 0; a.drop_scale = 1.f; a.drop_k0 = a.drop_k1 = a.drop_off = 0;
+    if (drop_p != 0.f) {
+        if (!fed || !backward || !(drop_p > 0.f) || !(drop_p < 1.f)) return PGASR_ERR_INVALID_ARG;
+        a.drop_on = 1;
+        a.drop_thresh = (uint32_t)fmin(4294967295.0, (double)drop_p * 4294967296.0);      // as pgasr_dropout
+        a.drop_scale = 1.f / (1.f - drop_p);
+        a.drop_k0 = (uint32_t)(drop_seed & 0xffffffffu); a.drop_k1 = (uint32_t)(drop_seed >> 32); a.drop_off = drop_offset;
     }
     dim3 grid((G_CLUSTER + a.n_helpers) * l.NCL8);   // + the helper workgroups of each cluster
     if (backward) PGASR_LAUNCH_KERNEL(lstm_bwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
@@ -1049,6 +1094,20 @@ extern "C" int pgasr_lstm_layer_fwd_fed(float* gates, float* out, float* cbuf, c
     if (!fed) return PGASR_ERR_INVALID_ARG;
     return lstm_launch(false, gates, out, cbuf, nullptr, nullptr, whh_pack_fwd, lengths, T, B, flags, workspace, workspace_bytes,
                        (hipStream_t)stream, fed, fed_need);
+}
+
+// Backward sweep whose dout rows are produced WHILE it runs: dout = the input gradient of the layer above, written by
+// pgasr_gemm_x3w_feed_f32(order = 1) after this call; fed_need = 2H/256 column tiles per direction.  drop_p != 0: dout
+// arrives WITHOUT the inter-layer dropout mask (model.py:42) and the helpers apply pgasr_dropout(p, seed, offset)'s
+// mask to the rows they stage (dout itself keeps the unmasked values).
+extern "C" int pgasr_lstm_layer_bwd_fed(float* gates, const float* out, const float* cbuf, const float* dout,
+                                        const void* whh_pack_bwd, const int32_t* lengths, int T, int B, int flags,
+                                        float* dbias_part, const unsigned* fed, int fed_need, float drop_p, uint64_t drop_seed,
+                                        uint32_t drop_offset, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!fed) return PGASR_ERR_INVALID_ARG;
+    if (dbias_part && (((size_t)dbias_part) & 15)) return PGASR_ERR_INVALID_ARG;
+    return lstm_launch(true, gates, const_cast<float*>(out), const_cast<float*>(cbuf), dout, dbias_part, whh_pack_bwd, lengths, T, B,
+                       flags, workspace, workspace_bytes, (hipStream_t)stream, fed, fed_need, drop_p, drop_seed, drop_offset);
 }
 
 extern "C" int pgasr_lstm_fed_ok(int T, int B, int flags) {

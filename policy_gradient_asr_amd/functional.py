@@ -8,6 +8,7 @@ from . import hipops
 
 HID = hipops.HID
 FEED_AHEAD = os.environ.get("PGASR_FEED_AHEAD", "1") != "0"   # input projections run beside the forward sweeps they feed
+FEED_BWD = os.environ.get("PGASR_FEED_BWD", "1") != "0"       # .. and the upper layers' input-gradient GEMMs beside the backward sweeps
 LEAKY_SLOPE = 0.01   # F.leaky_relu default, model.py:50
 
 
@@ -56,14 +57,17 @@ class grad_overlap:
     def pending(cls):
         return cls._pendings.setdefault(cls._key(), [])
 
+    # input gradients that are produced LATE (BLSTMLayerFn.backward): data_ptr of the placeholder tensor -> record
+    _deferred = {}
+
     @classmethod
-    def flush(cls, busy_ptr=0, launched_after=None):
+    def flush(cls, busy_ptr=0, launched_after=None, first=None):
         """Issue the deferred weight-gradient GEMMs on the side stream.  Called right after a sweep kernel
         has been launched: a kernel with a large grid enqueued BEFORE the sweep holds up the dispatch of
         everything behind it, on any stream (rocprof: the sweep's 5 us memset waited 616 us for the GEMM
         in front of it), so the order of enqueueing is sweep first, GEMMs second."""
         pending = cls.pending()
-        if not pending:
+        if not pending and first is None:
             return
         side = cls.side_stream()
         prev = hipops.GEMM_XCC_BUSY_PTR
@@ -77,6 +81,8 @@ class grad_overlap:
                     # on the main stream just before the sweep, then for the sweep's clusters to register
                     side.wait_event(launched_after)
                     hipops.stream_gate(busy_ptr)
+                if first is not None:
+                    first()          # the GEMM that feeds the sweep just launched goes ahead of the weight gradients
                 for ready, fn in pending:
                     fn()
         finally:
@@ -85,6 +91,9 @@ class grad_overlap:
 
     @classmethod
     def finish(cls):
+        if cls._deferred:
+            cls._deferred.clear()
+            raise RuntimeError("a deferred input gradient was never consumed by a BLSTM layer (grad_overlap/FEED_AHEAD)")
         cls.flush()
         if cls._key() in cls._sides:
             torch.cuda.current_stream().wait_stream(cls.side_stream())
@@ -153,6 +162,10 @@ class DropoutFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         p, seed, offset = ctx.cfg
+        rec = grad_overlap._deferred.get(dy.data_ptr())
+        if rec is not None and not ctx.fused and rec["drop"] is None and dy.shape == rec["dx"].shape:
+            rec["drop"] = (p, seed, offset)      # the sweep that consumes dy applies this mask while it stages the rows
+            return (dy, None, None, None) + (None,) * ctx.nopt
         dact = ctx.saved_tensors[0] if ctx.fused else None
         return (hipops.dropout(dy.contiguous(), p, seed, offset, dact_y=dact, slope=LEAKY_SLOPE), None, None, None) + (None,) * ctx.nopt
 
@@ -270,15 +283,25 @@ class BLSTMLayerFn(torch.autograd.Function):
         G = 2 * 4 * HID
         dev = x.device
         dout = dout.contiguous()
+        rec = grad_overlap._deferred.pop(dout.data_ptr(), None) if grad_overlap.enabled else None
         if grad_overlap.enabled:
             before = torch.cuda.Event()
             before.record()
-        _, dbias_part = hipops.lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=True)   # gates := dgates
+        if rec is not None:
+            # dout does not exist yet: the layer above left its input-gradient GEMM (and the dropout between the layers)
+            # to us.  The sweep goes first; the GEMM follows on the side stream and feeds it row tile by row tile.
+            _, dbias_part = hipops.lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=True,
+                                                  fed=rec["done"], fed_need=rec["need"], drop=rec["drop"])
+        else:
+            _, dbias_part = hipops.lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=True)   # gates := dgates
         dg = gates
         if grad_overlap.enabled:
             # the layer above left its weight-gradient GEMMs for now: they run beside THIS sweep, whose clusters
             # register the XCDs they occupy in busy counters that the queue-mode GEMM workgroups consult
-            grad_overlap.flush(hipops.lstm_busy_ptr(T, B, True, dev), launched_after=before)
+            busy = hipops.lstm_busy_ptr(T, B, True, dev)
+            grad_overlap.flush(busy, launched_after=before, first=(lambda: rec["launch"](busy)) if rec is not None else None)
+            if rec is not None:
+                dout.record_stream(grad_overlap.side_stream())
             swept = torch.cuda.Event()
             swept.record()
             if not ctx.sweep_follows and grad_overlap.upper_grads_hook is not None:
@@ -286,7 +309,23 @@ class BLSTMLayerFn(torch.autograd.Function):
                 # (N > 1: the trainer starts their all-reduce there, behind this sweep and under the tail GEMMs)
                 grad_overlap.upper_grads_hook(swept)
         dx = None
-        if ctx.needs_input_grad[0]:
+        defer = (ctx.needs_input_grad[0] and grad_overlap.enabled and FEED_AHEAD and FEED_BWD and ctx.sweep_follows and not ctx.has_dact
+                 and ctx.planes_t is not None and hipops.gemm_x3w_ok(T * B, I, G) and I % 256 == 0 and I == 2 * HID
+                 and hipops.lstm_fed_ok(T, B))
+        if defer:
+            # another layer's backward sweep consumes dx (through at most a dropout): leave the product to that layer's
+            # backward, which launches its sweep FIRST and lets this GEMM feed it from the side stream
+            dx = torch.empty(T, B, I, dtype=torch.float32, device=dev)
+            done = torch.zeros(2 * ((T * B + 255) // 256), dtype=torch.int32, device=dev)
+            planes_t = ctx.planes_t
+
+            def launch(busy_ptr, dg=dg, dx=dx, done=done, planes_t=planes_t):
+                hipops.gemm_x3w_feed(dg, planes_t, dx, T * B, I, G, None, busy_ptr, done, order=1)
+                side_ = torch.cuda.current_stream()
+                for t_ in (dg, dx, done) + tuple(planes_t):
+                    t_.record_stream(side_)
+            grad_overlap._deferred[dx.data_ptr()] = {"dx": dx, "done": done, "need": I // 256, "drop": None, "launch": launch}
+        elif ctx.needs_input_grad[0]:
             dx = torch.empty(T, B, I, dtype=torch.float32, device=dev)
             if ctx.planes_t is not None and hipops.gemm_x3w_ok(T * B, I, G):
                 hipops.gemm_x3w(dg, ctx.planes_t, dx, T * B, I, G,

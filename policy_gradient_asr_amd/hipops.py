@@ -387,7 +387,7 @@ def lstm_fed_ok(T, B):
     return bool(_lib.load().pgasr_lstm_fed_ok(T, B, LSTM_FLAGS))
 
 
-def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done):
+def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done, order=0):
     """``gemm_x3w`` in feed-ahead mode on the CURRENT stream (see include/pgasr_hip.h, pgasr_gemm_x3w_feed_f32)."""
     lib = _lib.load()
     hi, lo = planes
@@ -400,20 +400,30 @@ def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done):
         raise _lib.PgasrError("gemm_x3w_feed: tiles_done must hold 2 * ceil(M/256) int32 words")
     ws = _workspace(256, C.device, "x3w_feed")
     st = lib.pgasr_gemm_x3w_feed_f32(M, N, K, A.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), C.data_ptr(), N, _p(bias),
-                                     busy_ptr, tiles_done.data_ptr(), _p(ws), ws.numel(), _stream())
+                                     busy_ptr, tiles_done.data_ptr(), int(order), _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_gemm_x3w_feed_f32")
     return C
 
 
-def lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=False):
+def lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=False, fed=None, fed_need=0, drop=None):
     """gates := d(pre-activation gates).  want_dbias: also returns the (ceil(B/16), 2*4H) per-group bias-gradient
-    partial sums the sweep accumulates on the way (sum its rows)."""
+    partial sums the sweep accumulates on the way (sum its rows).
+    fed: counters of a ``gemm_x3w_feed(order=1)`` launched AFTER this call that fills ``dout`` while the sweep runs;
+    drop = (p, seed, offset): dout arrives without that dropout mask, the sweep's helpers apply it."""
     lib = _lib.load()
     ws = _lstm_ws(T, B, True, gates.device)
     part = torch.empty((B + 15) // 16, 2 * 4 * HID, dtype=torch.float32, device=gates.device) if want_dbias else None
     with _timed("lstm_bwd_kernel"):
-        st = lib.pgasr_lstm_layer_bwd(_p(gates), _p(out), _p(cbuf), _p(dout), _p(pack_b), _p(lengths), T, B, LSTM_FLAGS,
-                                      _p(part), _p(ws), ws.numel(), _stream())
+        if fed is None:
+            st = lib.pgasr_lstm_layer_bwd(_p(gates), _p(out), _p(cbuf), _p(dout), _p(pack_b), _p(lengths), T, B, LSTM_FLAGS,
+                                          _p(part), _p(ws), ws.numel(), _stream())
+        else:
+            if fed.dtype != torch.int32 or not fed.is_cuda or fed.numel() < 2 * ((T * B + 255) // 256):
+                raise _lib.PgasrError("lstm_layer_bwd: fed must be an int32 GPU tensor of 2 * ceil(T*B/256) words")
+            p, seed, offset = drop if drop is not None else (0.0, 0, 0)
+            st = lib.pgasr_lstm_layer_bwd_fed(_p(gates), _p(out), _p(cbuf), _p(dout), _p(pack_b), _p(lengths), T, B, LSTM_FLAGS,
+                                              _p(part), _p(fed), int(fed_need), float(p), int(seed), int(offset),
+                                              _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_lstm_layer_bwd")
     return (ws, part) if want_dbias else ws
 

@@ -257,6 +257,30 @@ def test_two_bucket_allreduce_on_a_single_rank_rccl_group():
         dist.destroy_process_group()
 
 
+def test_feed_ahead_gemms_give_identical_train_steps():
+    """functional.FEED_AHEAD: input projections run beside the forward sweeps they feed, the upper layers' input-gradient
+    GEMMs beside the backward sweeps they feed with the inter-layer dropout mask applied by the sweep's helper
+    workgroups.  Train mode (dropout on): gradients and parameters equal the sequential order bit for bit."""
+    from policy_gradient_asr_amd import functional as Fh
+    prev = Fh.FEED_AHEAD
+    res = []
+    try:
+        for feed in (False, True):
+            Fh.FEED_AHEAD = feed
+            tr, batch = _trainer_and_batch(train=True)
+            tr.step(*batch)
+            torch.cuda.synchronize()
+            g1 = tr.gflat.clone()
+            tr.step(*batch)
+            torch.cuda.synchronize()
+            res.append((g1, tr.gflat.clone(), tr.flat.clone()))
+    finally:
+        Fh.FEED_AHEAD = prev
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert float(res[0][0].abs().sum()) > 0
+
+
 def test_train_mode_step_runs_with_dropout():
     from policy_gradient_asr_amd.model import Seq2Seq, weights
     from policy_gradient_asr_amd.train_step import PolicyGradientTrainer
