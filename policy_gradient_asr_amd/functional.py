@@ -251,7 +251,7 @@ class BLSTMLayerFn(torch.autograd.Function):
             # the projection leaves the critical path: the sweep is launched FIRST and its helper workgroups wait for
             # the row tiles a GEMM on the side stream produces, in consumption order, on the XCDs the sweep leaves free
             main = torch.cuda.current_stream()
-            side = grad_overlap.side_stream()
+            side = grad_overlap.second_side_stream()     # not the stream the weight packs of the later layers are queued on
             done = torch.zeros(2 * ((T * B + 255) // 256), dtype=torch.int32, device=x.device)
             zeroed = torch.cuda.Event()
             zeroed.record()
