@@ -248,6 +248,11 @@ int pgasr_lstm_busy_offset(int B, int backward, size_t* offset);   /* 8 per-XCD 
  * GEMMs that are to run BESIDE a sweep, so that the sweep's workgroups are dispatched first (a large grid
  * enqueued ahead of the sweep delays it by the whole GEMM).  A hint only: never affects results. */
 int pgasr_stream_gate(const unsigned* words, int count, int timeout_us, void* stream);
+/* One wave on `stream` waits (at most timeout_us <= 1e6) for words[0] != 0 and then writes words[1] = 1 if it saw it, else
+ * 0.  Set words[0] from ANOTHER stream after this call: words[1] tells whether the two streams really run concurrently
+ * (they do not under kernel-serialising profilers / launch-blocking modes / a single hardware queue).  The fed sweeps
+ * below REQUIRE that concurrency; callers probe once per stream pair and otherwise use the sequential order. */
+int pgasr_stream_probe(unsigned* words, int timeout_us, void* stream);
 int pgasr_lstm_layer_fwd(float* gates, float* out, float* cbuf, const void* whh_pack_fwd,
                          const int32_t* lengths, int T, int B, int flags,
                          void* workspace, size_t workspace_bytes, void* stream);

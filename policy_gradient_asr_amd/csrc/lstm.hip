@@ -1155,6 +1155,31 @@ __global__ void __launch_bounds__(64) stream_gate_kernel(const unsigned* words, 
 }
 }  // namespace
 
+namespace {
+// words[1] = 1 iff words[0] became non-zero within the time-out: did a kernel on ANOTHER stream run while this one was
+// resident?  (Kernel serialisation -- counter-collecting profilers, launch-blocking debug modes, a single hardware
+// queue -- would make a fed sweep wait for a GEMM that cannot start; callers probe once and fall back.)
+__global__ void __launch_bounds__(64) stream_probe_kernel(unsigned* words, long long timeout_ticks) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    unsigned seen = 0;
+    for (;;) {
+        seen = __hip_atomic_load(words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        POLL_FENCE();
+        if (seen != 0u || wall_clock64() - t0 > timeout_ticks) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    __hip_atomic_store(words + 1, seen != 0u ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+}  // namespace
+
+extern "C" int pgasr_stream_probe(unsigned* words, int timeout_us, void* stream) {
+    if (!words || timeout_us <= 0 || timeout_us > 1000000) return PGASR_ERR_INVALID_ARG;
+    PGASR_LAUNCH_KERNEL(stream_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, (long long)timeout_us * 100);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
+
 extern "C" int pgasr_stream_gate(const unsigned* words, int count, int timeout_us, void* stream) {
     if (!words || count <= 0 || count > 64 || timeout_us < 0 || timeout_us > 100000) return PGASR_ERR_INVALID_ARG;
     PGASR_LAUNCH_KERNEL(stream_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, count, (long long)timeout_us * 100);

@@ -247,7 +247,7 @@ class BLSTMLayerFn(torch.autograd.Function):
         out = torch.empty(T, B, 2 * HID, dtype=torch.float32, device=x.device)
         cbuf = torch.empty(T, B, 2 * HID, dtype=torch.float32, device=x.device)
         x3w = prepacked.planes is not None and hipops.gemm_x3w_ok(T * B, G, I)   # LDS-DMA kernel, pre-split weight planes
-        if x3w and FEED_AHEAD and hipops.lstm_fed_ok(T, B):
+        if x3w and FEED_AHEAD and hipops.lstm_fed_ok(T, B) and hipops.streams_concurrent(grad_overlap.second_side_stream()):
             # the projection leaves the critical path: the sweep is launched FIRST and its helper workgroups wait for
             # the row tiles a GEMM on the side stream produces, in consumption order, on the XCDs the sweep leaves free
             main = torch.cuda.current_stream()
@@ -311,7 +311,7 @@ class BLSTMLayerFn(torch.autograd.Function):
         dx = None
         defer = (ctx.needs_input_grad[0] and grad_overlap.enabled and FEED_AHEAD and FEED_BWD and ctx.sweep_follows and not ctx.has_dact
                  and ctx.planes_t is not None and hipops.gemm_x3w_ok(T * B, I, G) and I % 256 == 0 and I == 2 * HID
-                 and hipops.lstm_fed_ok(T, B))
+                 and hipops.lstm_fed_ok(T, B) and hipops.streams_concurrent(grad_overlap.side_stream()))
         if defer:
             # another layer's backward sweep consumes dx (through at most a dropout): leave the product to that layer's
             # backward, which launches its sweep FIRST and lets this GEMM feed it from the side stream

@@ -504,6 +504,27 @@ def lstm_busy_ptr(T, B, backward, device, stream=None):
     return ws.data_ptr() + off.value
 
 
+_concurrent = {}
+
+
+def streams_concurrent(other):
+    """True iff kernels on ``other`` run while a kernel of the CURRENT stream is resident (probed once per stream pair,
+    synchronises).  The feed-ahead GEMMs need this: with serialised kernels (counter-collecting profilers,
+    HIP_LAUNCH_BLOCKING, one hardware queue) a fed sweep would wait for a GEMM that cannot start."""
+    main = torch.cuda.current_stream()
+    key = (main.cuda_stream, other.cuda_stream)
+    if key not in _concurrent:
+        lib = _lib.load()
+        words = torch.zeros(2, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        torch.cuda.synchronize()
+        _lib.check(lib.pgasr_stream_probe(words.data_ptr(), 20000, _stream()), "pgasr_stream_probe")
+        with torch.cuda.stream(other):
+            words[0:1].fill_(1)
+        torch.cuda.synchronize()
+        _concurrent[key] = bool(int(words[1].item()) == 1)
+    return _concurrent[key]
+
+
 def stream_gate(words_ptr, count=8, timeout_us=60):
     """Hold the current stream until a sweep has registered in the busy counters at ``words_ptr``."""
     lib = _lib.load()

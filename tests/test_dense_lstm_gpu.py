@@ -208,6 +208,8 @@ def test_blstm_fed_by_concurrent_projection_matches_sequential(T, B, lens):
     projection-then-sweep order; B > 32 falls back to the sequential order by itself."""
     from policy_gradient_asr_amd import functional as Fh, hipops
     assert hipops.lstm_fed_ok(T, B) and not hipops.lstm_fed_ok(T, 33)
+    if not hipops.streams_concurrent(Fh.grad_overlap.second_side_stream()):
+        pytest.skip("kernels of different streams are serialised here (profiler / launch-blocking): feed-ahead is off by itself")
     lstm, x, dy, lengths = _lstm_case(T, B, lens, seed=7 + T)
     names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0",
              "weight_ih_l0_reverse", "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]

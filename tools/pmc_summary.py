@@ -21,7 +21,7 @@ def one(pattern):
 
 
 def short(name):
-    for key in ("lstm_fwd_kernel", "lstm_bwd_kernel", "gemm_bf16x3_kernel", "gemm_f32_kernel", "gemm_reduce_kernel",
+    for key in ("lstm_fwd_kernel", "lstm_bwd_kernel", "gemm_x3w_kernel", "gemm_bf16x3_kernel", "gemm_f32_kernel", "gemm_reduce_kernel",
                 "ctc_lattice_kernel", "ctc_grad_kernel", "edit_distance_kernel"):
         if key in name:
             return key
