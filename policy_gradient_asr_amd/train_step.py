@@ -176,6 +176,9 @@ class PolicyGradientTrainer(DataParallelStep):
         grad_overlap.upper_grads_hook = self._upper_grads_issued if early else None
         try:
             loss.backward()
+        except BaseException:
+            grad_overlap._deferred.clear()      # do not let finish() mask the error with its own complaint
+            raise
         finally:
             grad_overlap.enabled = False
             grad_overlap.upper_grads_hook = None
