@@ -517,11 +517,15 @@ def streams_concurrent(other):
         lib = _lib.load()
         words = torch.zeros(2, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
         torch.cuda.synchronize()
-        _lib.check(lib.pgasr_stream_probe(words.data_ptr(), 20000, _stream()), "pgasr_stream_probe")
+        _lib.check(lib.pgasr_stream_probe(words.data_ptr(), 200000, _stream()), "pgasr_stream_probe")
         with torch.cuda.stream(other):
             words[0:1].fill_(1)
         torch.cuda.synchronize()
         _concurrent[key] = bool(int(words[1].item()) == 1)
+        if not _concurrent[key]:
+            import warnings
+            warnings.warn("policy_gradient_asr_amd: kernels of different streams do not run concurrently here "
+                          "(serialising profiler / launch-blocking mode / one hardware queue): feed-ahead GEMMs are off")
     return _concurrent[key]
 
 
