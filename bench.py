@@ -149,6 +149,7 @@ def main():
     extra = {k: (v[0] * args.steps / 2.0, v[1] * args.steps / 2.0) for k, v in hipops.profile_collect().items() if k not in prof}
     prof.update(extra)
     hipops.profile_reset(False)
+    hipops.lstm_assert_no_timeouts()      # every rank: a timed-out sweep would make the number meaningless
     if world > 1:
         tt = torch.tensor([dt], device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

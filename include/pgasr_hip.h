@@ -242,6 +242,8 @@ int pgasr_lstm_unpack_grads(const float* dwih_perm, const float* dbias_perm, con
                             float* dw_ih_r, float* dw_hh_r, float* db_ih_r, float* db_hh_r,
                             int accumulate, void* stream);
 size_t pgasr_lstm_workspace_bytes(int T, int B, int backward);
+/* Byte offset of the workspace's error word: set to 1 when a bounded wait inside a sweep gives up (results invalid).
+ * The word is STICKY -- no launch clears it: zero the first 16 bytes of a workspace once after allocating it. */
 int pgasr_lstm_error_offset(int B, int backward, size_t* offset);
 int pgasr_lstm_busy_offset(int B, int backward, size_t* offset);   /* 8 per-XCD busy counters (hint for pgasr_gemm_f32) */
 /* Holds `stream` until any of words[0..count) is non-zero or timeout_us (<= 100000) has passed: put in front of

@@ -1033,9 +1033,10 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
     // every cluster must be co-resident, one workgroup per CU: at most 2 clusters per XCD
     if (2 * l.NBG > 16) return PGASR_ERR_UNSUPPORTED;
     char* ws = (char*)workspace;
-    // one launch: zero the head block (error flag, busy counters, hello and progress words) and set every exchange
-    // word to "stale for epoch 0" (bit0 = 1)
-    PGASR_LAUNCH_KERNEL(lstm_prepare_kernel, dim3(64), dim3(256), 0, st, (u32x4*)(ws + l.err), (unsigned)((l.xbuf - l.err) / 16),
+    // one launch: zero the head block (busy counters, hello and progress words) and set every exchange word to "stale
+    // for epoch 0" (bit0 = 1).  The first 16 bytes -- the error word -- are NOT touched: the flag is sticky, the owner of
+    // the workspace zeroes it once and a time-out in any later launch stays visible (pgasr_lstm_error_offset)
+    PGASR_LAUNCH_KERNEL(lstm_prepare_kernel, dim3(64), dim3(256), 0, st, (u32x4*)(ws + l.err + 16), (unsigned)((l.xbuf - l.err - 16) / 16),
                        (u32x4*)(ws + l.xbuf), (unsigned)(l.xbytes / 16));
     PGASR_CHECK_LAUNCH();
     LstmArgs a;

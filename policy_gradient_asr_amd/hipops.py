@@ -77,7 +77,9 @@ def _workspace(nbytes, device, tag):
     key = (tag, device, torch.cuda.current_stream().cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        # sweep workspaces start zeroed: their first word is a STICKY error flag (lstm_assert_no_timeouts)
+        alloc = torch.zeros if tag.startswith("lstm") else torch.empty
+        buf = alloc(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
 
@@ -437,6 +439,17 @@ def lstm_check_error(ws, B, backward):
     flag = int(ws[off.value:off.value + 4].view(torch.int32).item())
     if flag != 0:
         raise _lib.PgasrError("persistent LSTM sweep timed out waiting for its cluster (status 5)")
+
+
+def lstm_assert_no_timeouts():
+    """Host-side check of EVERY sweep workspace this process has used (synchronises): a persistent sweep that gave up
+    on a bounded wait -- its cluster, its helpers or the GEMM feeding it never showed up -- leaves its error word set
+    and its results are invalid.  Cheap enough for once per epoch / once per benchmark run."""
+    torch.cuda.synchronize()
+    bad = [key[0] for key, ws in _ws_cache.items()
+           if key[0].startswith("lstm") and int(ws[:4].view(torch.int32).item()) != 0]
+    if bad:
+        raise _lib.PgasrError(f"persistent LSTM sweep timed out (status 5) in workspace(s) {sorted(set(bad))}")
 
 
 # ------------------------------------------------------------------------------------------

@@ -200,6 +200,7 @@ def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset
             if log_every and step % log_every == 0:
                 print("Step {}/{}. Loss: {:>4f}".format(step, len(loader), float(loss)))
         losses.append(float(acc) / max(len(loader), 1))
+        hipops.lstm_assert_no_timeouts()          # a sweep that gave up on a wait must not pass silently
         np.save(os.path.join(model_path, "train_loss.npy"), np.array(losses))
         print("Epoch:{}/{} Training loss:{:>4f}".format(epoch, num_epochs, losses[-1]))
 
