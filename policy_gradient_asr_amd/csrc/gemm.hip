@@ -230,8 +230,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
 // the 3 terms).  fp32 accumulate; dropping lo*lo leaves ~2^-16 relative error per product
 // (measured ~1e-6 relative on the path's GEMMs).  LDS image per operand: [row][32 k + 8 pad] bf16,
 // k fastest, so a fragment is one aligned 16-byte read and 16 consecutive rows fall on distinct
-// banks; sources whose M/N index is contiguous (K x M weight-gradient operands) are transposed by
-// the staging writes.
+// banks; operands whose M/N index is contiguous in memory use the [k][m] image further down.
 // ------------------------------------------------------------------------------------------
 constexpr int XBK = 32, XPITCH = 40;   // halfs per LDS row
 
@@ -248,63 +247,34 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi_pk, unsi
     lo_pk = __builtin_bit_cast(unsigned, l);
 }
 
-// 16-float strip of a 128 x 32 operand tile.
-//   KCONTIG : thread -> (row = tid>>1, k0 = (tid&1)*16)
-//   !KCONTIG: thread -> (k = tid&31, row0 = (tid>>5)*16)
-template <bool KCONTIG>
+// 16-float strip of a 128 x 32 tile of a k-contiguous operand: thread -> (row = tid>>1, k0 = (tid&1)*16)
 __device__ __forceinline__ void xload_strip(const float* __restrict__ P, int ld, int mn_base, int mn_lim,
                                             int k_base, int k_lim, int tid, bool vec_ok, float v[16]) {
-    if (KCONTIG) {
-        const int mn = mn_base + (tid >> 1);
-        const int k0 = k_base + (tid & 1) * 16;
-        if (mn < mn_lim && k0 + 16 <= k_lim && vec_ok) {
-            const float4* p = reinterpret_cast<const float4*>(P + (size_t)mn * ld + k0);
+    const int mn = mn_base + (tid >> 1);
+    const int k0 = k_base + (tid & 1) * 16;
+    if (mn < mn_lim && k0 + 16 <= k_lim && vec_ok) {
+        const float4* p = reinterpret_cast<const float4*>(P + (size_t)mn * ld + k0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const float4 a = p[i]; v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = (mn < mn_lim && k0 + i < k_lim) ? P[(size_t)mn * ld + k0 + i] : 0.f;
-        }
+        for (int i = 0; i < 4; ++i) { const float4 a = p[i]; v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w; }
     } else {
-        const int k = k_base + (tid & 31);
-        const int mn0 = mn_base + (tid >> 5) * 16;
-        if (k < k_lim && mn0 + 16 <= mn_lim && vec_ok) {
-            const float4* p = reinterpret_cast<const float4*>(P + (size_t)k * ld + mn0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const float4 a = p[i]; v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = (k < k_lim && mn0 + i < mn_lim) ? P[(size_t)k * ld + mn0 + i] : 0.f;
-        }
+        for (int i = 0; i < 16; ++i) v[i] = (mn < mn_lim && k0 + i < k_lim) ? P[(size_t)mn * ld + k0 + i] : 0.f;
     }
 }
 
-template <bool KCONTIG>
 __device__ __forceinline__ void xstore_strip(unsigned short* hi, unsigned short* lo, int tid, const float v[16]) {
-    if (KCONTIG) {
-        const int row = tid >> 1, k0 = (tid & 1) * 16;
-        unsigned h[8], l[8];
+    const int row = tid >> 1, k0 = (tid & 1) * 16;
+    unsigned h[8], l[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) split2(v[2 * i], v[2 * i + 1], h[i], l[i]);
-        u32x4_t* ph = reinterpret_cast<u32x4_t*>(hi + row * XPITCH + k0);
-        u32x4_t* pl = reinterpret_cast<u32x4_t*>(lo + row * XPITCH + k0);
-        ph[0] = (u32x4_t){h[0], h[1], h[2], h[3]}; ph[1] = (u32x4_t){h[4], h[5], h[6], h[7]};
-        pl[0] = (u32x4_t){l[0], l[1], l[2], l[3]}; pl[1] = (u32x4_t){l[4], l[5], l[6], l[7]};
-    } else {
-        const int k = tid & 31, row0 = (tid >> 5) * 16;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            unsigned h, l;
-            split2(v[2 * i], v[2 * i + 1], h, l);
-            hi[(row0 + 2 * i) * XPITCH + k] = (unsigned short)h;
-            hi[(row0 + 2 * i + 1) * XPITCH + k] = (unsigned short)(h >> 16);
-            lo[(row0 + 2 * i) * XPITCH + k] = (unsigned short)l;
-            lo[(row0 + 2 * i + 1) * XPITCH + k] = (unsigned short)(l >> 16);
-        }
-    }
+    for (int i = 0; i < 8; ++i) split2(v[2 * i], v[2 * i + 1], h[i], l[i]);
+    u32x4_t* ph = reinterpret_cast<u32x4_t*>(hi + row * XPITCH + k0);
+    u32x4_t* pl = reinterpret_cast<u32x4_t*>(lo + row * XPITCH + k0);
+    ph[0] = (u32x4_t){h[0], h[1], h[2], h[3]}; ph[1] = (u32x4_t){h[4], h[5], h[6], h[7]};
+    pl[0] = (u32x4_t){l[0], l[1], l[2], l[3]}; pl[1] = (u32x4_t){l[4], l[5], l[6], l[7]};
 }
 
-// ---- TN products (both operands K x M/N with the M/N index contiguous: the weight gradients dW = dY^T X) ----
+// ---- operands stored K x M/N with the M/N index contiguous (A of a TN/TT product, B of a TN/NN product; both
+// operands of the weight gradients dW = dY^T X) ----
 // The LDS image keeps the global orientation, [k][128 m/n + 32 pad] bf16, and the MFMA fragments (8 consecutive k of
 // one row) come out of gfx950's transposing read ds_read_b64_tr_b16: the global loads are coalesced along m/n
 // (a half-wave reads 512 contiguous bytes of one k row), the staging writes are 8-byte (the [row][k] image above
@@ -412,7 +382,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(GemmArgs g
     // s_waitcnt: rocprofv3 SQ_WAIT_ANY, profiles/r01_gemm_pmc.txt).
     float ra0[16], rb0[16], ra1[16], rb1[16];
     const int fr = lane & 31, fk = (lane >> 5) * 8;
-    constexpr bool TNL = TA && !TB;      // transposing-read LDS image (see tload_strip)
+    // an operand whose M/N index is contiguous in memory (A stored K x M, B stored K x N) keeps that orientation in LDS
+    // and is read through the transposing instruction (see tload_strip); a k-contiguous operand uses the [row][k] image
+    constexpr bool TRA = TA, TRB = !TB;
     // lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3 of the group's 4 x 16 block; groups 0,1 take
     // columns 0-15 / 16-31 of k 0-7, groups 2,3 the same columns of k 8-15 (= the 32x32x16 operand map)
     const int tro = (8 * (lane >> 5) + ((lane & 15) >> 2)) * TPITCH + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -422,21 +394,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(GemmArgs g
             bf16x8_t ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                if constexpr (TNL) {
+                if constexpr (TRA) {
                     const int ro = kk * TPITCH + wm * 64 + i * 32 + tro;
                     ah[i] = tr_frag(&S[cur][0][0][ro]);
                     al[i] = tr_frag(&S[cur][0][1][ro]);
+                } else {
+                    const int ro = (wm * 64 + i * 32 + fr) * XPITCH + kk + fk;
+                    ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(&S[cur][0][0][ro]));
+                    al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(&S[cur][0][1][ro]));
+                }
+                if constexpr (TRB) {
                     const int co = kk * TPITCH + wn * 64 + i * 32 + tro;
                     bh[i] = tr_frag(&S[cur][1][0][co]);
                     bl[i] = tr_frag(&S[cur][1][1][co]);
-                    continue;
+                } else {
+                    const int co = (wn * 64 + i * 32 + fr) * XPITCH + kk + fk;
+                    bh[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(&S[cur][1][0][co]));
+                    bl[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(&S[cur][1][1][co]));
                 }
-                const int ro = (wm * 64 + i * 32 + fr) * XPITCH + kk + fk;
-                ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(&S[cur][0][0][ro]));
-                al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(&S[cur][0][1][ro]));
-                const int co = (wn * 64 + i * 32 + fr) * XPITCH + kk + fk;
-                bh[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(&S[cur][1][0][co]));
-                bl[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(&S[cur][1][1][co]));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -452,24 +427,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(GemmArgs g
     // the plain load under a wave-uniform branch (unconditional sub+mul cost every GEMM ~10 %), in-range only
     const int nrm = g.norm_operand;
     const float nsh = nrm ? g.shift[bidx] : 0.f, nsc = nrm ? g.scale[bidx] : 1.f;
-    auto norm_strip = [&](float (&v)[16], bool kcontig, int mn_base, int mn_lim, int kb) {
+    auto norm_strip = [&](float (&v)[16], bool tr, int mn_base, int mn_lim, int kb) {     // tr: the operand's strip mapping
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int mn = TNL ? mn_base + (tid & 31) * 4 + (i & 3) : kcontig ? mn_base + (tid >> 1) : mn_base + (tid >> 5) * 16 + i;
-            const int k = TNL ? kb + (tid >> 5) + 8 * (i >> 2) : kcontig ? kb + (tid & 1) * 16 + i : kb + (tid & 31);
+            const int mn = tr ? mn_base + (tid & 31) * 4 + (i & 3) : mn_base + (tid >> 1);
+            const int k = tr ? kb + (tid >> 5) + 8 * (i >> 2) : kb + (tid & 1) * 16 + i;
             v[i] = (mn < mn_lim && k < kend) ? (v[i] - nsh) * nsc : 0.f;
         }
     };
-#define XLOAD(RA, RB, KB) do { if constexpr (TNL) { tload_strip(A, g.lda, m0, g.M, (KB), kend, tid, vecA, RA); \
-                                                    tload_strip(B, g.ldb, n0, g.N, (KB), kend, tid, vecB, RB); } \
-                               else { xload_strip<!TA>(A, g.lda, m0, g.M, (KB), kend, tid, vecA, RA); \
-                                      xload_strip<TB>(B, g.ldb, n0, g.N, (KB), kend, tid, vecB, RB); } \
-                               if (nrm == 1) norm_strip(RA, !TA, m0, g.M, (KB)); \
-                               else if (nrm == 2) norm_strip(RB, TB, n0, g.N, (KB)); } while (0)
-#define XSTORE(RA, RB, BUF) do { if constexpr (TNL) { tstore_strip(S[BUF][0][0], S[BUF][0][1], tid, RA); \
-                                                      tstore_strip(S[BUF][1][0], S[BUF][1][1], tid, RB); } \
-                                 else { xstore_strip<!TA>(S[BUF][0][0], S[BUF][0][1], tid, RA); \
-                                        xstore_strip<TB>(S[BUF][1][0], S[BUF][1][1], tid, RB); } } while (0)
+#define XLOAD(RA, RB, KB) do { if constexpr (TRA) tload_strip(A, g.lda, m0, g.M, (KB), kend, tid, vecA, RA); \
+                               else xload_strip(A, g.lda, m0, g.M, (KB), kend, tid, vecA, RA); \
+                               if constexpr (TRB) tload_strip(B, g.ldb, n0, g.N, (KB), kend, tid, vecB, RB); \
+                               else xload_strip(B, g.ldb, n0, g.N, (KB), kend, tid, vecB, RB); \
+                               if (nrm == 1) norm_strip(RA, TRA, m0, g.M, (KB)); \
+                               else if (nrm == 2) norm_strip(RB, TRB, n0, g.N, (KB)); } while (0)
+#define XSTORE(RA, RB, BUF) do { if constexpr (TRA) tstore_strip(S[BUF][0][0], S[BUF][0][1], tid, RA); \
+                                 else xstore_strip(S[BUF][0][0], S[BUF][0][1], tid, RA); \
+                                 if constexpr (TRB) tstore_strip(S[BUF][1][0], S[BUF][1][1], tid, RB); \
+                                 else xstore_strip(S[BUF][1][0], S[BUF][1][1], tid, RB); } while (0)
     if (kbeg < kend) {
         XLOAD(ra0, rb0, kbeg);
         XSTORE(ra0, rb0, 0);
