@@ -232,6 +232,29 @@ def test_blstm_fed_by_concurrent_projection_matches_sequential(T, B, lens):
             assert torch.equal(a, b)
 
 
+def test_sweep_error_word_is_sticky_and_checked():
+    """A sweep that gives up on a bounded wait sets the first word of its workspace; no later launch clears it and
+    hipops.lstm_assert_no_timeouts() (called by bench.py and model.train) raises.  The flag is forged here."""
+    from policy_gradient_asr_amd import functional as Fh, hipops, _lib
+    T, B, lens = 6, 4, [6, 6, 5, 3]
+    lstm, x, dy, lengths = _lstm_case(T, B, lens, seed=3)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0",
+             "weight_ih_l0_reverse", "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+    params = [getattr(lstm, n).detach().to(DEV) for n in names]
+    run = lambda: Fh.blstm_layer(x.to(DEV), lengths.to(torch.int32).to(DEV), params)
+    run()
+    hipops.lstm_assert_no_timeouts()
+    ws = hipops._lstm_ws(T, B, False, torch.device(DEV))
+    ws[:4].view(torch.int32).fill_(1)
+    try:
+        run()                                        # a later launch must not wipe the flag
+        with pytest.raises(_lib.PgasrError):
+            hipops.lstm_assert_no_timeouts()
+    finally:
+        ws[:4].zero_()
+    hipops.lstm_assert_no_timeouts()
+
+
 def test_encoder_matches_reference_golden(golden_dir):
     """Encoder on the MI355X vs the reference model.Encoder outputs (tests/golden)."""
     from policy_gradient_asr_amd.model import Encoder
