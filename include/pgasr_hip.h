@@ -181,10 +181,16 @@ int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, const unsig
  * halves: row tile i of direction 0 together with row tile last-i of direction 1), store C write-through and count
  * finished tiles in tiles_done[2][ceil(M/256)] (zeroed by the caller BEFORE the sweep is launched; a word is
  * complete at N/256).  xcc_busy = the sweep's busy counters (pgasr_lstm_busy_offset): workgroups on a busy XCD
- * take no tile, a second unmasked launch picks up any rest.  workspace >= 256 bytes.  Call order on the host:
+ * take no tile, a second unmasked launch picks up any rest.  workspace >= 1024 bytes; with
+ * pgasr_gemm_x3w_feed_workspace_bytes() (32 MB) the first 16 tile groups -- the ones the sweep is waiting for -- are
+ * computed as four parallel K-quarters and summed in index order by the last arrival (a tile otherwise takes one CU
+ * K/32 x 1.7 us).  The x3w products DEFINE their result as ((q0 + q1) + q2) + q3 over K-quarters accumulated from
+ * zero whenever K >= 1024 and K % 128 == 0, in pgasr_gemm_x3w_f32 as well, so both orders give the same bits.
+ * Call order on the host:
  * zero tiles_done -> pgasr_lstm_layer_fwd_fed (stream S) -> pgasr_stream_gate + this call (another stream that
  * waits for the zeroing).  order 0: rows in the order a forward sweep consumes them; 1: a backward sweep's (the
  * product is then the input gradient of the layer above, feeding pgasr_lstm_layer_bwd_fed).  Needs N % 256 == 0 on top of pgasr_gemm_x3w_f32's conditions and M*ldc*4 < 2^31. */
+size_t pgasr_gemm_x3w_feed_workspace_bytes(void);
 int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
                             const unsigned short* Wlo, float* C, int ldc, const float* bias,
                             const unsigned* xcc_busy, unsigned* tiles_done, int order, void* workspace,

@@ -53,6 +53,7 @@ SIGNATURES = {
     "pgasr_split_bf16_planes": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr]),
     "pgasr_gemm_x3w_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_ptr, c_ptr, c_f32p, C.c_int,
                                      c_f32p, c_f32p, C.c_float, c_ptr]),
+    "pgasr_gemm_x3w_feed_workspace_bytes": (C.c_size_t, []),
     "pgasr_gemm_x3w_feed_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_ptr, c_ptr, c_f32p, C.c_int,
                                           c_f32p, c_ptr, c_ptr, C.c_int, c_ptr, C.c_size_t, c_ptr]),
     "pgasr_feat_frames": (C.c_int, [c_f32p, c_i32p, c_i32p, C.c_int, C.c_longlong, C.c_int, c_f32p, c_ptr]),

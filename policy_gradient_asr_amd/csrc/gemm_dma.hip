@@ -48,6 +48,14 @@ struct DmaGemmArgs {
     const unsigned* xcc_busy;   // [8] per-XCD count of sweep clusters, or nullptr (sweeper pass: any XCD)
     unsigned* tiles_done;       // [2][mt_count]: finished column tiles per (direction half of N, row tile)
     int mt_count, nt_count, order;   // order 0: forward-sweep consumption order, 1: backward-sweep order (mirrored)
+    // K in quarters (both kernels): the result is DEFINED as ((q0 + q1) + q2) + q3 with every quarter accumulated from
+    // zero, so that a tile whose quarters are computed by four workgroups in parallel (the first split_tiles tiles of a
+    // feed: a sweep is waiting for them, and one workgroup needs K/32 x 1.7 us for a tile) gives the same bits as a
+    // tile computed by one workgroup
+    int quarters;               // 1 or 4
+    int split_tiles;            // FEED: tiles (in queue order) whose quarters are separate work items
+    float* slabs;               // FEED: [split_tiles][4][64][512] partial accumulators
+    unsigned* arrive;           // FEED: [split_tiles] quarters finished (zeroed by the host)
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_base) {
@@ -129,14 +137,19 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_x3w_kernel(DmaGemmArgs g) {
     }
   for (;;) {
     int tbx, tby;
+    int kt0 = 0, kt1 = nk, qpart = -1;      // k-tile range of this work item; qpart >= 0: one quarter of a split tile
+    unsigned tile = 0;
     if (FEED) {
         unsigned* mailbox = reinterpret_cast<unsigned*>(smem + NST * STAGE_BYTES);   // 16 bytes past the stages
         if (tid == 0) *mailbox = __hip_atomic_fetch_add(g.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const unsigned t = *mailbox;
         __syncthreads();
-        if (t >= (unsigned)g.mt_count * (unsigned)g.nt_count) return;
-        const int half = g.nt_count >> 1, grp = (int)(t / (unsigned)g.nt_count), j = (int)(t % (unsigned)g.nt_count);
+        const unsigned S = (unsigned)g.split_tiles, ntot = (unsigned)g.mt_count * (unsigned)g.nt_count;
+        if (t >= ntot + 3u * S) return;             // 4 S quarter items, then the remaining ntot - S whole tiles
+        if (t < 4u * S) { tile = t >> 2; qpart = (int)(t & 3u); kt0 = qpart * (nk >> 2); kt1 = kt0 + (nk >> 2); }
+        else tile = t - 3u * S;
+        const int half = g.nt_count >> 1, grp = (int)(tile / (unsigned)g.nt_count), j = (int)(tile % (unsigned)g.nt_count);
         tbx = j;
         tby = ((j < half) != (g.order != 0)) ? grp : g.mt_count - 1 - grp;
     } else {
@@ -200,10 +213,26 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_x3w_kernel(DmaGemmArgs g) {
     // LDS, VALU and the load path are all within 2x of each other, so no single reordering wins; the next step is a
     // bf16-plane activation format written by the producers (pure bf16 GEMM over 3K, 128x64 per wave).
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    issue(0, 0);
-    issue(1, 1);
+    f32x16 total[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) total[i][j][r] = 0.f;
+    const int kq = g.quarters == 4 ? (nk >> 2) : nk;       // k-tiles per quarter
+    issue(kt0, 0);
+    issue(kt0 + 1, 1);
     int stage = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < kt1; ++kt) {
+        if (kt != kt0 && kt % kq == 0) {                    // quarter boundary inside one workgroup's walk over K
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { total[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
+        }
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -230,6 +259,46 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_x3w_kernel(DmaGemmArgs g) {
         stage = stage + 1 < NST ? stage + 1 : 0;
     }
 
+    if (FEED && qpart >= 0) {
+        // one quarter of a split tile: park the accumulators (thread-major: a wave instruction stores 256 contiguous
+        // bytes) write-through, count the arrival; the LAST of the four sums the quarters in index order and goes on to
+        // the epilogue, the others take their next work item
+        __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(g.slabs, 0, (int)((size_t)g.split_tiles * 4 * 64 * 512 * 4), 0x00020000);
+        const unsigned sb = (tile * 4u + (unsigned)qpart) * 64u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), srs, ((sb + (unsigned)((i * 2 + j) * 16 + r)) * 512u + (unsigned)tid) * 4u, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* mailbox = reinterpret_cast<unsigned*>(smem + NST * STAGE_BYTES);
+        if (tid == 0) *mailbox = __hip_atomic_fetch_add(g.arrive + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned before = *mailbox;
+        __syncthreads();
+        if (before != 3u) continue;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        total[i][j][r] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                            srs, (((tile * 4u + (unsigned)qq) * 64u + (unsigned)((i * 2 + j) * 16 + r)) * 512u + (unsigned)tid) * 4u, 0, 16));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) total[i][j][r] += acc[i][j][r];
+    }
+
     // epilogue: 32x32 accumulator layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int cl = lane & 31, rq = lane >> 5;
     __amdgpu_buffer_rsrc_t crs;
@@ -244,7 +313,7 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_x3w_kernel(DmaGemmArgs g) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
                 if (m >= g.M) continue;
-                float v = acc[i][j][r] + bsum;
+                float v = total[i][j][r] + bsum;
                 if (g.dact_y) v *= (g.dact_y[(size_t)m * g.ldc + n] > 0.f ? 1.f : g.slope);
                 if (FEED) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crs, (unsigned)(((size_t)m * g.ldc + n) * 4), 0, 16);
                 else g.C[(size_t)m * g.ldc + n] = v;
@@ -287,6 +356,11 @@ extern "C" int pgasr_split_bf16_planes(const float* src, int rows, int cols, int
     return PGASR_OK;
 }
 
+static int x3w_quarters(int K) { return (K >= 1024 && K % (4 * TK) == 0) ? 4 : 1; }   // a quarter of >= 8 k-tiles
+constexpr int FEED_SPLIT_MAX = 64;       // split tiles per feed: 4 x 64 slabs of 128 KB = 32 MB of workspace
+
+extern "C" size_t pgasr_gemm_x3w_feed_workspace_bytes(void) { return 1024 + (size_t)FEED_SPLIT_MAX * 4 * 64 * 512 * 4; }
+
 extern "C" int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
                                   const unsigned short* Wlo, float* C, int ldc, const float* bias,
                                   const float* dact_y, float slope, void* stream) {
@@ -298,7 +372,7 @@ extern "C" int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, 
     const size_t lds = (size_t)NST * STAGE_BYTES;   // 144 KB of the CU's 160 KB: opt in per call (idempotent, no state kept)
     if (hipFuncSetAttribute((const void*)gemm_x3w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
-    DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, dact_y, slope, nullptr, nullptr, nullptr, 0, 0, 0};
+    DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, dact_y, slope, nullptr, nullptr, nullptr, 0, 0, 0, x3w_quarters(K), 0, nullptr, nullptr};
     PGASR_LAUNCH_KERNEL(gemm_x3w_kernel<false>, dim3((unsigned)(N / TN), gy), dim3(DMA_THREADS), lds, (hipStream_t)stream, g);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
@@ -312,14 +386,15 @@ extern "C" int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, 
 //                busy XCD take no tile; a second, unmasked launch picks up whatever is left (normally nothing)
 //   order      : 0 = rows in the order a FORWARD sweep consumes them (direction 0 ascending in t, direction 1
 //                descending), 1 = the order of a BACKWARD sweep (mirrored)
-//   workspace  : >= 256 bytes (tile counter)
+//   workspace  : >= 1024 bytes (tile and arrival counters); with pgasr_gemm_x3w_feed_workspace_bytes() the first tiles
+//                are computed as four parallel K-quarters (same bits, a quarter of the latency)
 extern "C" int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
                                        const unsigned short* Wlo, float* C, int ldc, const float* bias,
                                        const unsigned* xcc_busy, unsigned* tiles_done, int order, void* workspace,
                                        size_t workspace_bytes, void* stream) {
     if (!A || !Whi || !Wlo || !C || !tiles_done || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N) return PGASR_ERR_INVALID_ARG;
     if (order < 0 || order > 1) return PGASR_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < 256) return PGASR_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < 1024) return PGASR_ERR_WORKSPACE;
     if ((K % TK) || (N % (2 * TN)) || (lda & 3) || (((size_t)A) & 15) || (((size_t)Whi) & 15) || (((size_t)Wlo) & 15))
         return PGASR_ERR_UNSUPPORTED;
     if ((size_t)M * ldc * 4 >= ((size_t)1 << 31)) return PGASR_ERR_UNSUPPORTED;      // buffer-addressed stores
@@ -328,8 +403,20 @@ extern "C" int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int 
     if (hipFuncSetAttribute((const void*)gemm_x3w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, 256, st) != hipSuccess) return PGASR_ERR_LAUNCH;
-    DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, nullptr, 0.f, (unsigned*)workspace, xcc_busy, tiles_done, mt, nt, order};
+    if (hipMemsetAsync(workspace, 0, 1024, st) != hipSuccess) return PGASR_ERR_LAUNCH;   // tile counter + arrival counters
+    // the first tile groups (16 time-ordered groups, at most FEED_SPLIT_MAX tiles and what the workspace holds) are split
+    // into K-quarters: the sweep is waiting for exactly these
+    const int quarters = x3w_quarters(K);
+    int split = 0;
+    if (quarters == 4) {
+        const size_t room = (workspace_bytes - 1024) / ((size_t)4 * 64 * 512 * 4);
+        split = 16 * nt;
+        if (split > FEED_SPLIT_MAX) split = FEED_SPLIT_MAX;
+        if ((size_t)split > room) split = (int)room;
+        if (split > mt * nt) split = mt * nt;
+    }
+    DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, nullptr, 0.f, (unsigned*)workspace, xcc_busy, tiles_done, mt, nt, order,
+                  quarters, split, (float*)((char*)workspace + 1024), (unsigned*)workspace + 64};
     // one persistent workgroup per CU (144 KB of LDS each); pass 1 ignores the busy counters
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) g.xcc_busy = nullptr;

@@ -400,7 +400,7 @@ def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done, order=0):
         raise _lib.PgasrError("gemm_x3w_feed planes must be contiguous int16 (N, K)")
     if tiles_done.dtype != torch.int32 or tiles_done.numel() < 2 * ((M + 255) // 256):
         raise _lib.PgasrError("gemm_x3w_feed: tiles_done must hold 2 * ceil(M/256) int32 words")
-    ws = _workspace(256, C.device, "x3w_feed")
+    ws = _workspace(lib.pgasr_gemm_x3w_feed_workspace_bytes(), C.device, "x3w_feed")
     st = lib.pgasr_gemm_x3w_feed_f32(M, N, K, A.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), C.data_ptr(), N, _p(bias),
                                      busy_ptr, tiles_done.data_ptr(), int(order), _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_gemm_x3w_feed_f32")
