@@ -242,6 +242,8 @@ class BLSTMLayerFn(torch.autograd.Function):
             torch.cuda.current_stream().wait_event(prepacked.ready)
         wih_perm, bias_perm, pack_f, pack_b = prepacked.wih_perm, prepacked.bias_perm, prepacked.pack_f, prepacked.pack_b
         ctx.planes_t = prepacked.planes_t
+        ctx.fed_bwd = prepacked.fed_bwd       # zeroed counters for this layer's deferred input-gradient GEMM (or None)
+        prepacked.fed_bwd = None
         G = 2 * 4 * HID
         gates = torch.empty(T, B, G, dtype=torch.float32, device=x.device)
         out = torch.empty(T, B, 2 * HID, dtype=torch.float32, device=x.device)
@@ -252,7 +254,11 @@ class BLSTMLayerFn(torch.autograd.Function):
             # the row tiles a GEMM on the side stream produces, in consumption order, on the XCDs the sweep leaves free
             main = torch.cuda.current_stream()
             side = grad_overlap.second_side_stream()     # not the stream the weight packs of the later layers are queued on
-            done = torch.zeros(2 * ((T * B + 255) // 256), dtype=torch.int32, device=x.device)
+            need_words = 2 * ((T * B + 255) // 256)
+            done = prepacked.fed_fwd if (prepacked.fed_fwd is not None and prepacked.fed_fwd.numel() >= need_words) else None
+            prepacked.fed_fwd = None          # single use
+            if done is None:
+                done = torch.zeros(need_words, dtype=torch.int32, device=x.device)
             zeroed = torch.cuda.Event()
             zeroed.record()
             hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, fed=done, fed_need=G // 256)
@@ -316,7 +322,11 @@ class BLSTMLayerFn(torch.autograd.Function):
             # another layer's backward sweep consumes dx (through at most a dropout): leave the product to that layer's
             # backward, which launches its sweep FIRST and lets this GEMM feed it from the side stream
             dx = torch.empty(T, B, I, dtype=torch.float32, device=dev)
-            done = torch.zeros(2 * ((T * B + 255) // 256), dtype=torch.int32, device=dev)
+            need_words = 2 * ((T * B + 255) // 256)
+            done = ctx.fed_bwd if (ctx.fed_bwd is not None and ctx.fed_bwd.numel() >= need_words) else None
+            ctx.fed_bwd = None                # single use: a second backward through this node zeroes its own
+            if done is None:
+                done = torch.zeros(need_words, dtype=torch.int32, device=dev)
             planes_t = ctx.planes_t
 
             def launch(busy_ptr, dg=dg, dx=dx, done=done, planes_t=planes_t):
@@ -396,7 +406,7 @@ class BLSTMLayerFn(torch.autograd.Function):
 
 class PackedBLSTM:
     """What a sweep needs of one layer's parameters, in kernel layouts (made once per step)."""
-    __slots__ = ("wih_perm", "bias_perm", "pack_f", "pack_b", "planes", "planes_t", "ready")
+    __slots__ = ("wih_perm", "bias_perm", "pack_f", "pack_b", "planes", "planes_t", "ready", "fed_fwd", "fed_bwd")
 
 
 def prepack_blstm(params, in_dim):
@@ -408,19 +418,28 @@ def prepack_blstm(params, in_dim):
     pk.planes = hipops.split_planes(pk.wih_perm) if ok else None                      # (G, in): forward projection
     pk.planes_t = hipops.split_planes(pk.wih_perm, transpose=True) if ok else None    # (in, G): input gradient
     pk.ready = None
+    pk.fed_fwd = pk.fed_bwd = None      # pre-zeroed tile counters for the feed-ahead GEMMs of this step (prepack_blstm_layers)
     return pk
 
 
-def prepack_blstm_layers(layer_params, in_dims):
+def prepack_blstm_layers(layer_params, in_dims, rows=0):
     """All layers' packs on the side stream (they depend on the parameters only); each carries the event the
-    consuming stream waits for."""
+    consuming stream waits for.  rows = T*B > 0: the step's feed-ahead tile counters are zeroed here as well (one fill
+    for all layers, off the main stream) instead of one fill in front of every fed sweep."""
     main = torch.cuda.current_stream()
     side = grad_overlap.side_stream()
     side.wait_stream(main)          # the parameters may still be being written (previous step's Adam)
     out = []
     with torch.cuda.stream(side):
-        for params, in_dim in zip(layer_params, in_dims):
+        nl = len(in_dims)
+        words = 2 * ((rows + 255) // 256)
+        counters = torch.zeros(2 * nl, max(words, 1), dtype=torch.int32, device=layer_params[0][0].device) if rows > 0 else None
+        if counters is not None:
+            counters.record_stream(main)
+        for li, (params, in_dim) in enumerate(zip(layer_params, in_dims)):
             pk = prepack_blstm(params, in_dim)
+            if counters is not None:
+                pk.fed_fwd, pk.fed_bwd = counters[2 * li], counters[2 * li + 1]
             pk.ready = torch.cuda.Event()
             pk.ready.record()
             for t in (pk.wih_perm, pk.bias_perm, pk.pack_f, pk.pack_b) + (pk.planes or ()) + (pk.planes_t or ()):

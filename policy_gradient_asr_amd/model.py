@@ -65,7 +65,8 @@ class Encoder(nn.Module):
         training = self.training
         # weight repacking (gate-permuted W_ih, its bf16 planes, the register-resident W_hh packs) depends on the
         # parameters only: all three layers' packs are made on a side stream while the front end runs
-        packs = Fh.prepack_blstm_layers([self._layer_params(l) for l in range(3)], [512, 512, 512])
+        packs = Fh.prepack_blstm_layers([self._layer_params(l) for l in range(3)], [512, 512, 512],
+                                        rows=x.shape[0] * x.shape[2])
         # the affine's leaky'(y) factor is applied by whoever consumes y in the backward pass: the dropout that
         # follows it (train) or the first layer's input-gradient GEMM epilogue (eval)
         y = Fh.InstNormAffineFn.apply(x.float(), self.input_layer.weight, self.input_layer.bias, True)
