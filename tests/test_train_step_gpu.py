@@ -234,7 +234,10 @@ def test_two_bucket_allreduce_on_a_single_rank_rccl_group():
     import socket
     import torch.distributed as dist
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    except Exception as e:  # noqa: BLE001 - an environment without a usable RCCL transport is not a product failure
+        pytest.skip(f"cannot create a 1-rank RCCL group here: {e}")
     try:
         flats = []
         for collective in (False, True):
