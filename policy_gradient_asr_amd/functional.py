@@ -366,7 +366,7 @@ class BLSTMLayerFn(torch.autograd.Function):
                 dwhh.record_stream(cur)
             dwih = torch.empty(G, I, dtype=torch.float32, device=dev)
             hipops.gemm(dg, x, dwih, M=G, N=I, K=T * B, transA=True, lda=G,
-                        splitk=_pick_splitk(G, I, T * B, 256 if hh_stream is not None else 512))    # three GEMMs wide in the tail: fewer, longer slabs (tail 0.86 -> 0.83 ms)
+                        splitk=_pick_splitk(G, I, T * B, 512 if ctx.sweep_follows else 256))    # first layer: three GEMMs share the chip in the tail -> fewer, longer slabs (0.86 -> 0.83 ms); by layer, not by mode, so that overlap on/off give the same bits
             dbias = torch.empty(G, dtype=torch.float32, device=dev)
             hipops.colsum(dbias_part, dbias_part.shape[0], G, G, dbias)      # the sweep summed dgates over t per group
             if hh_stream is not None:
