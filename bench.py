@@ -1,10 +1,22 @@
 #!/usr/bin/env python3
 """bench.py --gpus N --steps K --warmup W : utterances/sec of one policy-gradient train step
 (BASELINE.json metric) on synthetic (B=32 per GPU, T=1000, F=80, V=29) data, one process per GPU.
-Prints ONE JSON line on rank 0 (contract in the task statement)."""
+
+`python3 bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks ITSELF
+(fresh child processes, before this process makes any GPU call); under torchrun (WORLD_SIZE set) it is
+one of the ranks.  Rank 0 prints ONE JSON line (contract in the task statement).
+
+Workloads:
+  headline  configs[2]+[1]: CTC + REINFORCE step, greedy (self-critical) baseline, lengths = T
+  bucketed  configs[4]   : the reference's own reward hypothesis (prefix beam search, beam 16,
+                           policy_grad.py:6-8) + variable lengths U[T/2,T] in length-bucketed batches,
+                           ranks balanced by frames
+"""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -13,67 +25,317 @@ sys.path.insert(0, ROOT)
 # The step uses three streams (main, weight-gradient side stream, CTC lattice) and RCCL adds its own: HIP's default of
 # 4 hardware queues makes streams share a queue and serialise behind each other.  Read by the runtime at start-up.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL across processes)
 
-import torch  # noqa: E402
+import torch  # noqa: E402  (importing torch does not touch the GPU)
 import torch.distributed as dist  # noqa: E402
 
 B_PER_GPU, T, F, V, L = 32, 1000, 80, 29, 100
+METRIC = "utterances/sec (B=32,T=1000,F=80) policy-grad step, 1/2/4/8 MI355X"
+DTYPE = "bf16x3 (fp32 storage and accumulate; every dense product = 3 bf16 MFMA terms hi*hi+hi*lo+lo*hi of a 2-plane split)"
+BF16_DENSE_PEAK_TF = 2500.0       # MI355X_MICROARCH.md, dense
+FP32_MFMA_PEAK_TF = 157.3
+STEP_GFLOP_PER_UTT = 28.65        # dense contraction forward + backward, T=1000
 
 
-def synth_batch(device, seed):
+# ------------------------------------------------------------------------------------------------
+# self-launch: N ranks as child processes of a parent that never touches the GPU
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """Parent of a `--gpus n` run without torchrun: start n children (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set), pass
+    their output through, exit with the first non-zero code.  No HIP call is made here (device_count() does not
+    initialise the GPU on this image), and nothing is exec'ed from a process that has."""
+    rehearse = os.environ.get("PGASR_BENCH_REHEARSE", "") == "1"
+    ndev = torch.cuda.device_count()
+    if ndev < n and not rehearse:
+        print(f"[bench] --gpus {n} but only {ndev} GPU(s) are visible", file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PGASR_BENCH_CHILD="1")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                deadline = time.time() + 20          # a dead rank leaves the others stuck in a collective
+                for q in alive:
+                    q.terminate()
+                for q in alive:
+                    try:
+                        q.wait(max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic batches (SURVEY §8d): features N(0,1), targets U{1..V-1}, L = T/10
+# ------------------------------------------------------------------------------------------------
+def synth_batch(seed, lengths=None, pin=False):
+    """Host-side batch in the collate_custom layout after model.py:227-230's squeeze: x (B,F,Tmax) fp32 zero past each
+    length, targets (B,Lmax) int64 pad 0, fmask (B,Tmax), tmask (B,Lmax)."""
     g = torch.Generator().manual_seed(seed)
-    x = torch.randn(B_PER_GPU, F, T, generator=g)
-    targets = torch.randint(1, V, (B_PER_GPU, L), generator=g)
-    fmask = torch.ones(B_PER_GPU, T)
-    tmask = torch.ones(B_PER_GPU, L, dtype=torch.int64)
-    return [t.to(device) for t in (x, targets, fmask, tmask)]
+    if lengths is None:
+        lengths = [T] * B_PER_GPU
+    nb = len(lengths)
+    tmax = max(lengths)
+    tl = [max(1, n // 10) for n in lengths]
+    lmax = max(tl)
+    x = torch.randn(nb, F, tmax, generator=g)
+    targets = torch.randint(1, V, (nb, lmax), generator=g)
+    fmask = torch.zeros(nb, tmax)
+    tmask = torch.zeros(nb, lmax, dtype=torch.int64)
+    for b, (n, m) in enumerate(zip(lengths, tl)):
+        fmask[b, :n] = 1
+        x[b, :, n:] = 0
+        tmask[b, :m] = 1
+        targets[b, m:] = 0
+    out = [x, targets, fmask, tmask]
+    return [t.pin_memory() for t in out] if pin else out
 
 
-def cpu_baseline(steps=1):
-    """The oracle's train step (torch-CPU model + ctc_loss + numpy decode/edit distance) on this
-    box's host cores.  Lengths are all T, so the unpacked LSTM is the same arithmetic as the
-    reference's packed call (SURVEY §6 variant ii)."""
-    import numpy as np
-    from oracle import model_ref, decode_ref
+def bucketed_pool(rank, world, n_batches, seed=0):
+    """configs[4]: a corpus of n_batches * global_batch utterances with lengths U[T/2,T]; global batches from the
+    length-bucketing sampler (data.LengthBucketSampler, replaces shuffle=True of model.py:221); each global batch is
+    dealt to the ranks by train_step.balance_by_frames.  Returns this rank's per-step length lists."""
+    from policy_gradient_asr_amd.data import LengthBucketSampler
+    from policy_gradient_asr_amd.train_step import balance_by_frames
+    g = torch.Generator().manual_seed(seed)
+    gb = B_PER_GPU * world
+    lens = torch.randint(T // 2, T + 1, (n_batches * gb,), generator=g).tolist()
+    sampler = LengthBucketSampler(lens, gb, bucket_batches=max(1, n_batches // 2), seed=seed, drop_last=True)
+    out = []
+    for idx in sampler:
+        mine = balance_by_frames([lens[i] for i in idx], world)[rank]
+        out.append([lens[idx[i]] for i in mine])
+    return out
+
+
+class BatchFeeder:
+    """The H2D copy of every step's batch happens INSIDE the timed region: pinned host tensors, copied on a copy stream
+    into one of two device buffer sets one step ahead of their use (DataLoader(pin_memory) + non_blocking, the
+    production pattern), or on the main stream at the start of the step (`serial`)."""
+
+    def __init__(self, host_batches, dev, mode, trainer):
+        self.host, self.dev, self.mode = host_batches, dev, mode
+        # prefetch: no stream of its own (see PolicyGradientTrainer.staging_stream); dma_prefetch: the textbook copy stream
+        self.copy = trainer.staging_stream() if mode == "prefetch" else (torch.cuda.Stream(device=dev) if mode == "dma_prefetch" else None)
+        self.kernel_copy = not mode.startswith("dma")
+        mx = [max(hb[i].numel() for hb in host_batches) for i in range(4)]      # flat buffers: every batch is a contiguous view
+        self.bufs = [[torch.empty(mx[i], dtype=host_batches[0][i].dtype, device=dev) for i in range(4)] for _ in range(2)]
+        self.ready = [None, None]
+        self.freed = [None, None]
+        self.k = 0
+        if self.copy is not None:
+            self._issue(0)
+
+    def _views(self, slot, hb):
+        return [self.bufs[slot][i][:hb[i].numel()].view(hb[i].shape) for i in range(4)]
+
+    def _copy(self, slot, hb):
+        from policy_gradient_asr_amd import hipops
+        for dst, src in zip(self._views(slot, hb), hb):
+            if self.kernel_copy:
+                hipops.stream_copy(dst, src)                # pgasr_stream_copy: asynchronous for the host
+            else:
+                dst.copy_(src, non_blocking=True)           # hipMemcpyAsync: returns when the DMA has run (measured)
+
+    def _issue(self, k):
+        slot, hb = k % 2, self.host[k % len(self.host)]
+        with torch.cuda.stream(self.copy):
+            if self.freed[slot] is not None and self.mode == "dma_prefetch":
+                self.copy.wait_event(self.freed[slot])      # the step that last used this buffer set has finished
+            # (the staging stream is ordered behind the previous step by construction: it joined the main stream there)
+            self._copy(slot, hb)
+            ev = torch.cuda.Event()
+            ev.record()
+        self.ready[slot] = ev
+
+    def next(self):
+        k, slot = self.k, self.k % 2
+        hb = self.host[k % len(self.host)]
+        main = torch.cuda.current_stream()
+        if self.copy is not None:
+            main.wait_event(self.ready[slot])
+            self.pending = k + 1                            # staged by done(), once this step has been enqueued
+        elif self.mode.endswith("serial"):
+            self._copy(slot, hb)
+        elif k < 2:                                         # "resident": inputs copied once, outside the timed steps
+            for dst, src in zip(self._views(slot, hb), hb):
+                dst.copy_(src)
+        self.k += 1
+        return self._views(slot, hb)
+
+    def done(self):
+        """Call after the step that consumed next()'s tensors has been enqueued."""
+        ev = torch.cuda.Event()
+        ev.record()
+        self.freed[(self.k - 1) % 2] = ev
+        if self.copy is not None:
+            self._issue(self.pending)
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU leg (rank 0, N=1 only): the oracle's train step timed on the host cores + one fp64 parity step
+# ------------------------------------------------------------------------------------------------
+def _cpu_cores():
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))   # the GPU box gives one GPU a 16-core share
+    return max(1, min(avail, 16))   # the GPU box gives one GPU a 16-core share
+
+
+def _cpu_step(model_ref, decode_ref, p, opt, x, targets, fmask, il, tl, packed, s):
+    import numpy as np
+    nb, lt = x.shape[0], targets.shape[1]
+    opt.zero_grad()
+    enc = model_ref.encoder_forward_torch(p, x, fmask, packed=packed)
+    logits = model_ref.head_logits_torch(p, enc)
+    lp = torch.log_softmax(logits, 2)
+    ctc = torch.nn.functional.ctc_loss(lp, targets, il, tl, blank=0, reduction="mean")
+    with torch.no_grad():
+        ln = logits.detach().numpy()
+        paths, _, _ = decode_ref.sample_paths(ln, seed=0, offset=s)
+        greedy = decode_ref.greedy_decode(ln)
+        adv = np.zeros(nb)
+        for b in range(nb):
+            y = targets[b].tolist()
+            rs = -decode_ref.edit_dist(y, decode_ref.collapse_path(paths[:, b]))[0] / lt
+            rg = -decode_ref.edit_dist(y, greedy[b])[0] / lt
+            adv[b] = rs - rg
+    lps = lp.gather(2, torch.from_numpy(paths).unsqueeze(-1)).squeeze(-1).sum(0)
+    loss = ctc - (torch.from_numpy(adv).float() * lps).sum() / nb
+    loss.backward()
+    opt.step()
+
+
+def cpu_baseline(steps=3):
+    """The oracle's train step (torch-CPU model + ctc_loss + numpy sampler/greedy/edit distance + Adam) on this box's
+    host cores, both variants of BASELINE.md §3:
+      (ii) unpacked LSTM at the full headline shape (lengths are all T, so it is the same arithmetic as the
+           reference's packed call) -- `value`, the honest bar;
+      (i)  the packed-sequence LSTM exactly as model.py:52-55 writes it, on a BOUNDED sample (T=250): torch's packed
+           CPU backward is O(T^2) (121 s per step at T=1000 on 8 cores), so the full shape cannot be timed
+           inside a default run."""
+    from oracle import model_ref, decode_ref
+    cores = _cpu_cores()
     torch.set_num_threads(cores)
-    p = {k: v.clone().requires_grad_(True) for k, v in model_ref.init_params(F, V, 0).items()}
-    opt = torch.optim.Adam(list(p.values()), lr=5e-4)
-    x, targets, fmask, tmask = synth_batch("cpu", 0)
-    il = torch.full((B_PER_GPU,), T, dtype=torch.long); tl = torch.full((B_PER_GPU,), L, dtype=torch.long)
-    times = []
-    for s in range(steps + 1):
-        t0 = time.perf_counter()
-        opt.zero_grad()
-        enc = model_ref.encoder_forward_torch(p, x, fmask, packed=False)
-        logits = model_ref.head_logits_torch(p, enc)
-        lp = torch.log_softmax(logits, 2)
-        ctc = torch.nn.functional.ctc_loss(lp, targets, il, tl, blank=0, reduction="mean")
-        with torch.no_grad():
-            ln = logits.detach().numpy()
-            paths, _, _ = decode_ref.sample_paths(ln, seed=0, offset=s)
-            greedy = decode_ref.greedy_decode(ln)
-            adv = np.zeros(B_PER_GPU)
-            for b in range(B_PER_GPU):
-                y = targets[b].tolist()
-                rs = -decode_ref.edit_dist(y, decode_ref.collapse_path(paths[:, b]))[0] / L
-                rg = -decode_ref.edit_dist(y, greedy[b])[0] / L
-                adv[b] = rs - rg
-        lps = lp.gather(2, torch.from_numpy(paths).unsqueeze(-1)).squeeze(-1).sum(0)
-        loss = ctc - (torch.from_numpy(adv).float() * lps).sum() / B_PER_GPU
-        loss.backward()
-        opt.step()
-        print(f"[bench] cpu baseline step {s}: {time.perf_counter() - t0:.2f} s", file=sys.stderr, flush=True)
-        if s > 0:
-            times.append(time.perf_counter() - t0)
-    sec = sum(times) / len(times)
+    out = {}
+    for name, packed, tt in (("unpacked", False, T), ("packed", True, T // 4)):
+        lt = tt // 10
+        p = {k: v.clone().requires_grad_(True) for k, v in model_ref.init_params(F, V, 0).items()}
+        opt = torch.optim.Adam(list(p.values()), lr=5e-4)
+        x, targets, fmask, _ = synth_batch(0, [tt] * B_PER_GPU)
+        il = torch.full((B_PER_GPU,), tt, dtype=torch.long)
+        tl = torch.full((B_PER_GPU,), lt, dtype=torch.long)
+        times = []
+        for s in range(steps + 1):
+            t0 = time.perf_counter()
+            _cpu_step(model_ref, decode_ref, p, opt, x, targets, fmask, il, tl, packed, s)
+            dt = time.perf_counter() - t0
+            print(f"[bench] cpu baseline ({name}, T={tt}) step {s}: {dt:.2f} s", file=sys.stderr, flush=True)
+            if s > 0:
+                times.append(dt)
+        times.sort()
+        out[name] = (times[len(times) // 2], tt, len(times))
+    sec, _, n = out["unpacked"]
+    psec, ptt, pn = out["packed"]
     return {"value": B_PER_GPU / sec, "unit": "utterances/sec", "cores": cores, "kind": "port",
-            "sample": f"{steps} full steps at B={B_PER_GPU},T={T},F={F},V={V} after 1 warm-up; torch-CPU LSTM "
-                      f"(unpacked, lengths=T) + ctc_loss + numpy sampler/greedy/edit distance + Adam; {sec:.2f} s/step"}
+            "sample": f"median of {n} full steps at B={B_PER_GPU},T={T},F={F},V={V} after 1 warm-up; torch-CPU LSTM "
+                      f"(unpacked, lengths=T: same arithmetic as the packed call) + ctc_loss + numpy sampler/greedy/"
+                      f"edit distance + Adam; {sec:.2f} s/step",
+            "variants": {
+                "unpacked_T1000": {"value": B_PER_GPU / sec, "s_per_step": sec, "steps": n},
+                "packed_as_written_T250_sample": {
+                    "value": B_PER_GPU / psec, "s_per_step": psec, "steps": pn,
+                    "note": f"model.py:52-55 pack_padded_sequence path, bounded sample B={B_PER_GPU},T={ptt},L={ptt // 10}; its "
+                            "CPU backward is O(T^2): at T=1000 the survey measured 121 s/step on 8 cores (0.26 utt/s)"}}}
+
+
+def parity_vs_fp64(model, trainer, batch):
+    """One UNTIMED eval-mode CTC step (lambda = 0, no sampling) of the benchmarked model on the GPU against the oracle in
+    fp64 on the same weights and inputs: relative error of the loss and max-norm relative error over all parameter
+    gradients.  Travels with the throughput number as its precision statement."""
+    from oracle import model_ref
+    from policy_gradient_asr_amd.loss import pg_ctc_loss
+    x, targets, fmask, tmask = batch
+    was_training = model.training
+    model.eval()
+    trainer.gflat.zero_()
+    logits, in_len = model.logits(x, fmask)
+    tg_len = tmask.sum(1).to(torch.int32).contiguous()
+    loss, _, _, _ = pg_ctc_loss(logits, in_len, targets.to(torch.int32).contiguous(), tg_len, lam=0.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    g_gpu = {k: v.grad.detach().double().cpu() for k, v in model.named_parameters()}
+    model.train(was_training)
+    torch.set_num_threads(_cpu_cores())
+    p = {(k[len("encoder."):] if k.startswith("encoder.") else k): v.detach().double().cpu().requires_grad_(True)
+         for k, v in model.named_parameters()}
+    t0 = time.perf_counter()
+    xc, fm = x.double().cpu(), fmask.cpu()
+    lens = fm.sum(1).long()
+    enc = model_ref.encoder_forward_torch(p, xc, fm, packed=bool((lens != xc.shape[2]).any()))
+    lp = torch.log_softmax(model_ref.head_logits_torch(p, enc), 2)
+    ref = torch.nn.functional.ctc_loss(lp, targets.cpu().long(), lens, tg_len.cpu().long(), blank=0, reduction="mean")
+    ref.backward()
+    print(f"[bench] fp64 parity step on the CPU: {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+    worst, worst_l2, worst_name = 0.0, 0.0, ""
+    for k, v in g_gpu.items():
+        rk = k[len("encoder."):] if k.startswith("encoder.") else k
+        r = p[rk].grad
+        e = float((v - r).abs().max() / (r.abs().max() + 1e-300))
+        worst_l2 = max(worst_l2, float((v - r).norm() / (r.norm() + 1e-300)))
+        if e > worst:
+            worst, worst_name = e, rk
+    return {"loss": abs(float(loss.detach()) - float(ref.detach())) / abs(float(ref.detach())), "param_grads_maxnorm": worst,
+            "param_grads_maxnorm_tensor": worst_name, "param_grads_frobenius": worst_l2,
+            "what": "eval-mode CTC step (lambda=0) of the benchmarked model (after the timed steps) vs torch-CPU fp64 on the same "
+                    "weights and batch; worst tensor.  The input layer's two tensors sit behind leaky_relu': a pre-activation "
+                    "that is zero to rounding changes side between two fp32 evaluations and moves one summand by 100x"}
+
+
+# ------------------------------------------------------------------------------------------------
+def allreduce_probe(trainer, dev, reps=10):
+    """Wall time of the step's two gradient buckets as stand-alone RCCL all-reduces (barrier-bracketed, outside the
+    timed region): what the early bucket hides under the tail of backward and what the late one adds."""
+    out = {}
+    split = trainer.upper_split or 0
+    scratch = torch.zeros_like(trainer.gflat)
+    for name, view in (("upper_bucket", scratch[split:]), ("rest_bucket", scratch[:split]), ("whole", scratch)):
+        if view.numel() == 0:
+            continue
+        for _ in range(2):
+            dist.all_reduce(view)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_reduce(view)
+        torch.cuda.synchronize()
+        dt = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], device=dev)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        out[name] = {"MB": view.numel() * 4 / 1e6, "ms": float(dt.item())}
+    return out
 
 
 def main():
@@ -81,24 +343,34 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=("headline", "bucketed"), default="headline")
+    ap.add_argument("--h2d", choices=("prefetch", "serial", "dma_prefetch", "dma_serial", "resident"), default="prefetch",
+                    help="how each step's batch reaches HBM inside the timed region (resident: not at all, diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # rehearsal switch for a 1-GPU box (never used by the driver): all ranks on cuda:0, gloo collectives
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} does not match the realised world size {world}", file=sys.stderr)
+        sys.exit(2)
+    # rehearsal switch for a 1-GPU box (never used by the driver): all ranks on cuda:0, gloo collectives staged
+    # through the host -- it exercises the launcher and the plumbing, it is NOT a scaling number
     rehearse = os.environ.get("PGASR_BENCH_REHEARSE", "") == "1"
     if rehearse:
         local_rank = 0
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
     if world > 1:
-        torch.cuda.set_device(local_rank)
         if rehearse:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+            dist.init_process_group("nccl", device_id=dev)
 
     from policy_gradient_asr_amd import hipops
     if rehearse:
@@ -110,7 +382,13 @@ def main():
     model = Seq2Seq(V, n_feats=F)
     model.apply(weights)
     model = model.to(dev).train()   # dropout on (model.py:45,51 p=0.5; model.py:42 p=0.3), as in training
-    trainer = PolicyGradientTrainer(model, lr=5e-4, lam=1.0, seed=1234, world_size=world, rank=rank)
+    bucketed = args.workload == "bucketed"
+    trainer = PolicyGradientTrainer(model, lr=5e-4, lam=1.0, seed=1234, world_size=world, rank=rank,
+                                    **({"reward_decoder": "beam", "beam_size": 16} if bucketed else {}))
+    # a silently slower configuration (feed-ahead fallen back to the sequential order because kernels of different
+    # streams do not overlap here) must not be benchmarked unnoticed; counter-collecting profiler passes serialise
+    # kernels by design and say so with PGASR_ALLOW_SEQUENTIAL=1
+    hipops.STRICT_CONCURRENCY = os.environ.get("PGASR_ALLOW_SEQUENTIAL", "") != "1"
     if rehearse and world > 1:
         _ar = dist.all_reduce
         def _cpu_all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):   # gloo has no device tensors here
@@ -120,15 +398,29 @@ def main():
         def _cpu_broadcast(t, src=0, group=None):
             c = t.cpu(); _bc(c, src=src, group=group); t.copy_(c)
         dist.broadcast = _cpu_broadcast
-    batch = synth_batch(dev, 100 + rank)
+
+    if bucketed:
+        pool = bucketed_pool(rank, world, n_batches=8, seed=0)
+        host = [synth_batch(1000 + 17 * i + rank, lens, pin=True) for i, lens in enumerate(pool)]
+        frames = [sum(lens) for lens in pool]
+    else:
+        host = [synth_batch(100 + rank, pin=True)]
+        frames = [B_PER_GPU * T]
+    feeder = BatchFeeder(host, dev, args.h2d, trainer)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def one_step():
+        batch = feeder.next()
+        loss = trainer.step(*batch)
+        feeder.done()
+        return loss
+
     for i in range(args.warmup):
-        trainer.step(*batch)
+        one_step()
         torch.cuda.synchronize()
         if rank == 0:
             print(f"[bench] warmup step {i} done", file=sys.stderr, flush=True)
@@ -136,61 +428,100 @@ def main():
     hipops.profile_reset(True, only=("lstm_",))     # live HIP-event timing of the dominant kernels (6 launches a step)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.step(*batch)
+        loss = one_step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
     if rank == 0:
-        print(f"[bench] timed region: {dt:.3f} s for {args.steps} steps", file=sys.stderr, flush=True)
+        print(f"[bench] timed region: {dt_local:.3f} s for {args.steps} steps", file=sys.stderr, flush=True)
     prof = hipops.profile_collect()
-    # the other instrumented kernels (GEMMs) are timed in two extra steps OUTSIDE the timed region
+    # the other instrumented kernels (GEMMs, beam search) are timed in two extra steps OUTSIDE the timed region
     hipops.profile_reset(True)
     for _ in range(2):
-        trainer.step(*batch)
+        one_step()
     extra = {k: (v[0] * args.steps / 2.0, v[1] * args.steps / 2.0) for k, v in hipops.profile_collect().items() if k not in prof}
     prof.update(extra)
     hipops.profile_reset(False)
     hipops.lstm_assert_no_timeouts()      # every rank: a timed-out sweep would make the number meaningless
+    dt = dt_local
+    per_rank_ms = [dt_local / args.steps * 1e3]
+    ar = None
     if world > 1:
-        tt = torch.tensor([dt], device=dev)
+        tt = torch.tensor([dt_local], device=dev)
+        if not rehearse:
+            gathered = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(gathered, tt)
+            per_rank_ms = [float(g.item()) / args.steps * 1e3 for g in gathered]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        if not rehearse:
+            ar = allreduce_probe(trainer, dev)
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = B_PER_GPU * world * args.steps / dt
         # dominant kernel: the LSTM sweep with the larger share
         sweeps = {k: v for k, v in prof.items() if k.startswith("lstm_")}
         name, (tot_ms, calls) = max(sweeps.items(), key=lambda kv: kv[1][0]) if sweeps else ("none", (0.0, 1))
-        flops_per_launch = 2.0 * 2 * B_PER_GPU * 256 * 1024 * T       # h(B,256) x W_hh^T(256,1024), 2 dirs, T steps
+        tavg = sum(frames) / len(frames) / B_PER_GPU                  # average steps of a sweep's chain
+        flops_per_launch = 2.0 * 2 * B_PER_GPU * 256 * 1024 * (T if not bucketed else tavg)   # h(B,256) x W_hh^T(256,1024), 2 dirs
         avg_ms = tot_ms / max(calls, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        peak = 157.3
-        traffic = None   # HBM bytes per launch of that kernel from the committed PMC passes (profiles/)
-        for fname in ("r01_pmc.json",):     # written by tools/pmc_summary.py
+        peak = BF16_DENSE_PEAK_TF / 3.0           # 3 bf16 MFMA products per algorithmic fp32 flop
+        traffic, traffic_src = None, None         # HBM bytes per launch of that kernel from the committed PMC passes
+        for fname in ("r02_pmc.json", "r01_pmc.json"):     # written by tools/pmc_summary.py
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as fi:
                     traffic = json.load(fi)["kernels"][name]["hbm_bytes_per_launch"]
+                traffic_src = f"from_committed_profile profiles/{fname} (separate --pmc passes; the profiler serialises kernels, " \
+                              "so that pass ran the sequential order of the same kernels)"
                 break
             except Exception:  # noqa: BLE001 - the file is optional evidence, never required to run
                 traffic = None
+        gflop_step_gpu = STEP_GFLOP_PER_UTT * (sum(frames) / len(frames) / T)     # per GPU: 28.65 GFLOP per 1000 frames
+        step_tf = gflop_step_gpu / (ms * 1e-3) / 1e3
         out = {
-            "metric": "utterances/sec (B=32,T=1000,F=80) policy-grad step, 1/2/4/8 MI355X",
+            "metric": METRIC,
             "value": value, "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]+[1]: CTC + REINFORCE train step (greedy baseline, sampled path, WER-style "
-                                   "edit-distance reward), B=32/GPU, T=1000, F=80, V=29, L=100, Adam",
-                       "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}", "dropout": "on (train mode)"},
+            "dtype": DTYPE, "data": "synthetic",
+            "config": {"workload": ("configs[2]+[1]: CTC + REINFORCE train step (greedy baseline, sampled path, WER-style "
+                                    "edit-distance reward), B=32/GPU, T=1000, F=80, V=29, L=100, Adam" if not bucketed else
+                                    "configs[4]: CTC + REINFORCE train step with the reference's reward hypothesis (prefix beam "
+                                    "search, beam 16, collapse_fn, edit distance), lengths U[500,1000] in length-bucketed "
+                                    "batches balanced by frames across ranks, B=32/GPU, F=80, V=29, L=T/10, Adam"),
+                       "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}", "dropout": "on (train mode)",
+                       "h2d": {"prefetch": "inside the timed region: the next step's pinned host batch is staged by pgasr_stream_copy on the CTC lattice's side stream, beside this step's backward pass",
+                               "serial": "inside the timed region: pinned host batch copied by pgasr_stream_copy on the main stream at step start",
+                               "dma_prefetch": "inside the timed region: hipMemcpyAsync one step ahead on a copy stream (blocks the host)",
+                               "dma_serial": "inside the timed region: hipMemcpyAsync on the main stream at step start (blocks the host)",
+                               "resident": "NOT in the timed region (diagnostic)"}[args.h2d],
+                       "frames_per_step_per_gpu": sum(frames) / len(frames)},
+            "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
+            "collective_backend": ("none" if world == 1 else ("gloo-rehearsal (NOT a scaling number)" if rehearse else "nccl (RCCL)")),
+            "ms_per_step_per_rank": per_rank_ms,
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "avg_launch_ms": avg_ms,
-                         "launches_per_step": calls / args.steps,
-                         "note": "serial chain of T dependent steps: latency bound, see DESIGN.md"},
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                         "avg_launch_ms": avg_ms, "launches_per_step": calls / args.steps,
+                         "algorithmic_gflop_per_launch": flops_per_launch / 1e9,
+                         "peak_note": "algorithmic fp32 flops against the bf16 dense MFMA peak / 3 (the kernel issues 3 bf16 "
+                                      "products per flop): identical to issued bf16 flops / 2500 TF",
+                         "issued_bf16_tflops": 3 * achieved, "issued_bf16_frac_of_2500": 3 * achieved / BF16_DENSE_PEAK_TF,
+                         "frac_vs_fp32_mfma_peak_157.3": achieved / FP32_MFMA_PEAK_TF,
+                         "note": "serial chain of T dependent cross-CU hand-offs: latency bound, see DESIGN.md"},
+            "roofline_step": {"algorithmic_tflops": step_tf, "gflop_per_step_per_gpu": gflop_step_gpu,
+                              "frac_vs_bf16x3_peak_833": step_tf / peak, "frac_vs_fp32_mfma_peak_157.3": step_tf / FP32_MFMA_PEAK_TF,
+                              "note": "whole-step dense contraction flops (SURVEY §8d: 28.65 GFLOP per 1000-frame utterance) per GPU / ms_per_step"},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "loss": float(loss.item()),
         }
+        if ar is not None:
+            out["allreduce_ms"] = ar
+        if world == 1 and not args.no_parity:
+            out["max_rel_err_vs_fp64"] = parity_vs_fp64(model, trainer, [t.to(dev) for t in host[0]])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

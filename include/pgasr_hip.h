@@ -37,7 +37,7 @@ typedef enum pgasr_status {
     PGASR_ERR_TIMEOUT = 5        /* a bounded in-kernel wait gave up (persistent LSTM) */
 } pgasr_status;
 
-#define PGASR_ABI_VERSION 1
+#define PGASR_ABI_VERSION 2
 
 int pgasr_abi_version(void);
 const char* pgasr_status_string(int status);
@@ -251,6 +251,11 @@ size_t pgasr_lstm_workspace_bytes(int T, int B, int backward);
 /* Byte offset of the workspace's error word: set to 1 when a bounded wait inside a sweep gives up (results invalid).
  * The word is STICKY -- no launch clears it: zero the first 16 bytes of a workspace once after allocating it. */
 int pgasr_lstm_error_offset(int B, int backward, size_t* offset);
+/* How a time-out reaches the caller: the launch calls themselves are asynchronous and return PGASR_OK; the sweep sets
+ * the sticky word.  pgasr_lstm_status synchronises `stream`, reads the word and returns PGASR_ERR_TIMEOUT when it is
+ * set (PGASR_OK otherwise); pgasr_adam_step takes the words' device addresses as guards and skips the update while
+ * one is set, so invalid gradients never reach the parameters between two host-side checks. */
+int pgasr_lstm_status(const void* workspace, size_t workspace_bytes, int B, int backward, void* stream);
 int pgasr_lstm_busy_offset(int B, int backward, size_t* offset);   /* 8 per-XCD busy counters (hint for pgasr_gemm_f32) */
 /* Holds `stream` until any of words[0..count) is non-zero or timeout_us (<= 100000) has passed: put in front of
  * GEMMs that are to run BESIDE a sweep, so that the sweep's workgroups are dispatched first (a large grid
@@ -295,10 +300,15 @@ int pgasr_lstm_layer_bwd(float* gates, const float* out, const float* cbuf, cons
  *   out_tokens (B,T) best prefix, out_len (B), out_score (B) = -logsumexp(p_blank, p_nonblank)
  *   of that prefix (CTCdecoder.py:115-116).  Candidate order, prefix merging and the stable
  *   descending sort (ties -> first insertion) follow the reference exactly; scores are fp64.
+ *   flags bit 0: out_tokens / out_len are given AFTER collapse_fn (adjacent duplicate symbols removed,
+ *   CTCdecoder.py:119-131) -- the string policy_grad.py:8 and model.py:326 score; bit 1: never take the
+ *   single-wave kernel.  fp32 input with beam <= 16, V <= 32 and T * beam <= 24576 (the reward hypothesis inside
+ *   the train step) runs as ONE WAVE per utterance with the prefix trie in LDS (no workspace traffic); the scores
+ *   of the two fp32 kernels agree to ~1e-7 relative, their hypotheses wherever no two candidates are closer than that.
  * ---------------------------------------------------------------------------------------- */
 size_t pgasr_beam_workspace_bytes(int T, int B, int V, int beam);
 int pgasr_ctc_beam_search(const void* log_probs, int is_f64, long long stride_t, long long stride_b,
-                          const int32_t* lengths, int T, int B, int V, int beam, int blank,
+                          const int32_t* lengths, int T, int B, int V, int beam, int blank, int flags,
                           int32_t* out_tokens, int32_t* out_len, double* out_score,
                           void* workspace, size_t workspace_bytes, void* stream);
 
@@ -311,12 +321,19 @@ int pgasr_ctc_beam_search(const void* log_probs, int is_f64, long long stride_t,
  *   dact_y (optional, n elements): the result is also multiplied by (dact_y > 0 ? 1 : slope) -- the backward
  *   of F.leaky_relu (model.py:50) fused into the backward of the dropout that follows it (model.py:51).
  * pgasr_adam_step: torch.optim.Adam update (model.py:207, lr=5e-4) on flat fp32 buffers;
- *   step is the 1-based step count used for bias correction.
+ *   step is the 1-based step count used for bias correction.  guard0 / guard1 (optional, device int32 words, e.g. the
+ *   sweep workspaces' error words): the update is skipped -- parameters and moments untouched -- while either is != 0.
  * ---------------------------------------------------------------------------------------- */
 int pgasr_dropout(const float* x, float* y, unsigned long long n, float p, uint64_t seed, uint32_t offset,
                   const float* dact_y, float slope, void* stream);
+/* A0 batch hand-over (model.py:227-230, `.to(device)`): copies `bytes` from src to dst (both 16-byte aligned) with
+ * `workgroups` (<= 1024) streaming workgroups on `stream`.  src may be pinned host memory that is mapped into the
+ * device's address space (hipHostMalloc, PyTorch's pinned tensors): the launch never blocks the host, and on a stream of
+ * its own the copy runs beside the train step instead of in front of it. */
+int pgasr_stream_copy(const void* src, void* dst, unsigned long long bytes, int workgroups, void* stream);
 int pgasr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, unsigned long long n,
-                    int step, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+                    int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    const int32_t* guard0, const int32_t* guard1, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * N3  feature front end (data.py:44-79): MFCC(40) + delta + delta-delta of torchaudio's defaults

@@ -16,6 +16,9 @@ def _device(device=None):
     return torch.device("cuda", torch.cuda.current_device())
 
 
+BEAM_KMAX = 128      # csrc/beam.hip
+
+
 class CTCDecoder:
     def __init__(self, alphabet, device=None):
         self.alphabet = alphabet
@@ -24,7 +27,9 @@ class CTCDecoder:
 
     def decode(self, probs, beam_size=100, blank=0):
         """probs: (time x output dim) array of PROBABILITIES (CTCdecoder.py:41-53).
-        Returns (label tuple, negative log-likelihood of that prefix)."""
+        Returns (label tuple, negative log-likelihood of that prefix).
+        Limits of the device search (the reference has none): beam_size <= 128 and at most 64 output symbols --
+        a larger request raises instead of silently searching a narrower beam."""
         dev = _device(self.device)
         probs = np.asarray(probs)
         T, V = probs.shape
@@ -33,7 +38,9 @@ class CTCDecoder:
         with np.errstate(divide="ignore"):
             logp = np.log(probs.astype(np.float64))          # like CTCdecoder.py:55
         lp = torch.from_numpy(np.ascontiguousarray(logp)).to(dev).view(T, 1, V)
-        tokens, tl, score = hipops.ctc_beam_search(lp, None, beam=min(int(beam_size), 128), blank=int(blank))
+        if int(beam_size) > BEAM_KMAX:
+            raise ValueError(f"beam_size {beam_size} exceeds the device search's limit of {BEAM_KMAX}")
+        tokens, tl, score = hipops.ctc_beam_search(lp, None, beam=int(beam_size), blank=int(blank))
         n = int(tl[0].item())
         return tuple(int(x) for x in tokens[0, :n].tolist()), float(score[0].item())
 

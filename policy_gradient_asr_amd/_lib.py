@@ -40,10 +40,11 @@ SIGNATURES = {
                                        c_f32p, c_ptr]),
     "pgasr_beam_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "pgasr_ctc_beam_search": (C.c_int, [c_ptr, C.c_int, C.c_longlong, C.c_longlong, c_i32p, C.c_int, C.c_int, C.c_int,
-                                        C.c_int, C.c_int, c_i32p, c_i32p, c_ptr, c_ptr, C.c_size_t, c_ptr]),
+                                        C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "pgasr_dropout": (C.c_int, [c_f32p, c_f32p, C.c_ulonglong, C.c_float, C.c_uint64, C.c_uint32, c_f32p, C.c_float, c_ptr]),
+    "pgasr_stream_copy": (C.c_int, [c_ptr, c_ptr, C.c_ulonglong, C.c_int, c_ptr]),
     "pgasr_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_ulonglong, C.c_int, C.c_float, C.c_float,
-                                  C.c_float, C.c_float, C.c_float, c_ptr]),
+                                  C.c_float, C.c_float, C.c_float, c_i32p, c_i32p, c_ptr]),
     "pgasr_gemm_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "pgasr_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                  c_f32p, C.c_int, C.c_longlong, c_f32p, C.c_int, C.c_longlong,
@@ -71,6 +72,7 @@ SIGNATURES = {
     "pgasr_lstm_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "pgasr_lstm_error_offset": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "pgasr_lstm_busy_offset": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "pgasr_lstm_status": (C.c_int, [c_ptr, C.c_size_t, C.c_int, C.c_int, c_ptr]),
     "pgasr_stream_gate": (C.c_int, [c_ptr, C.c_int, C.c_int, c_ptr]),
     "pgasr_stream_probe": (C.c_int, [c_ptr, C.c_int, c_ptr]),
     "pgasr_lstm_layer_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int,
@@ -87,6 +89,9 @@ SIGNATURES = {
 
 class PgasrError(RuntimeError):
     pass
+
+
+TIMEOUT = 5     # PGASR_ERR_TIMEOUT
 
 
 _lib = None
@@ -106,7 +111,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.pgasr_abi_version() != 1:
+    if lib.pgasr_abi_version() != 2:
         raise PgasrError("libpgasr_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -88,7 +88,7 @@ __device__ __forceinline__ bool item_less(const SortItem& a, const SortItem& b) 
 template <typename TIn, bool FAST>
 __global__ __launch_bounds__(BEAM_THREADS) void beam_search_kernel(
     const TIn* __restrict__ lp, long long stride_t, long long stride_b, const int32_t* __restrict__ lengths,
-    int T, int V, int K, int blank, BeamWs ws, int32_t* __restrict__ out_tokens, int32_t* __restrict__ out_len,
+    int T, int V, int K, int blank, int collapse, BeamWs ws, int32_t* __restrict__ out_tokens, int32_t* __restrict__ out_len,
     double* __restrict__ out_score) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -259,6 +259,12 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_search_kernel(
         int32_t* o = out_tokens + (size_t)b * T;
         int k = n - 1;
         for (int v = best; v > 0; v = (int)(nodes[v] >> 8)) o[k--] = (int32_t)(nodes[v] & 0xFFu);
+        if (collapse) {      // collapse_fn (CTCdecoder.py:119-131): adjacent duplicates removed
+            int w = 0;
+            for (int i = 0; i < n; ++i) if (i == 0 || o[i] != o[i - 1]) { const int32_t x = o[i]; o[w++] = x; }
+            for (int i = w; i < n; ++i) o[i] = 0;
+            out_len[b] = w;
+        }
         out_score[b] = -lse2x<FAST>(pb[cur * K], pnb[cur * K]);
     }
 }
@@ -277,6 +283,291 @@ inline size_t beam_lds_bytes(int K, int V) {
     return (n + 15) / 16 * 16;
 }
 
+
+// =====================================================================================================================
+// Small-beam search for the training path (reward hypothesis of policy_grad.py:6-8 inside the train step):
+// fp32 device log-probs, beam <= 16, V <= 32, T * beam <= 24576.  ONE WAVE per utterance, no workgroup barrier, no
+// LDS sort: the generic kernel above spends 24 us per frame in 45 LDS bitonic passes with barriers (24 ms for T = 1000);
+// a frame here is ~800 wave instructions.
+//
+//   lane = (q = lane / 16, j = lane % 16): entry j's state (p_b, p_nb, total, node id, last symbol, parent id) is
+//     replicated in the four 16-lane rows; lane (q, j) owns the candidates (entry j, symbol 8q + i), i < 8 -- the slot
+//     of the blank symbol holds entry j's "stay" candidate (prefix unchanged).
+//   scores: the same algebra as CTCdecoder.py:74-106 with the per-entry total lse(p_b, p_nb) factored out (an
+//     extension is total_j + log p(s), or p_b_j + log p(s) for a repeat of the last symbol; a stay collects blank,
+//     repeat and -- when entry j's parent i is in the beam -- the merged extension of i by last(j)); fp64 carries,
+//     fp32 exp/log on differences (like the generic fp32 path: ~1e-7 relative, so exact ties aside both rank alike).
+//   prefix identity: hash-consed trie in LDS.  A node's id IS its slot in one 32768-word open-addressing table whose
+//     word holds (parent id << 8 | symbol) + 1 -- table and node store in one array -- and, in bits 25..29, the beam
+//     position + 1 of the entry that currently carries that prefix: "is my parent in the beam, where?" is one LDS
+//     read, "which of my children are in the beam" one LDS atomic-or per entry.
+//   top-K: every candidate becomes a unique 64-bit key = order-preserving image of (score - best total) with the low
+//     17 mantissa bits replaced by [first-touch order of the reference's loop nest (:68,:74), slot, entry]: descending
+//     key order IS the reference's stable sort (:110-113).  Each lane sorts its 8 keys with a 19-exchange network in
+//     registers; K rounds of (row all-reduce max by DPP rotations on the high words, 4 readlanes, rarely a second pass
+//     on the low words) pop the winners in rank order; a lane's list beyond head/next waits in LDS.
+//   frames are staged 32 at a time through LDS, two chunks ahead in registers, so no load is ever waited for.
+// =====================================================================================================================
+namespace sb {
+constexpr int K_MAX = 16, V_MAX = 32, H = 32768, CH = 32;
+constexpr long long MAX_NODES = 24576;               // T * beam: load factor of the table <= 0.75
+constexpr unsigned ROOT = 0x8000u, NONE = 0xFFFFu, BAD_ID = 0x0FFFFFFFu;
+constexpr unsigned KEYMASK = 0x01FFFFFFu;
+constexpr size_t LDS_TABLE = (size_t)H * 4;          // 128 KB
+constexpr size_t LDS_FRAMES = (size_t)2 * CH * V_MAX * 4;
+constexpr size_t LDS_LIST = (size_t)6 * 64 * 8;
+constexpr size_t LDS_MM = 64;
+constexpr size_t LDS_BYTES = LDS_TABLE + LDS_FRAMES + LDS_LIST + LDS_MM;
+
+__device__ __forceinline__ double lse2f(double a, double b) {
+    // 1 + e^x with x <= 0 is in [1, 2]: the bare v_exp_f32 / v_log_f32 (base 2) need none of the library forms' range fix-ups
+    const double m = fmax(a, b), n = fmin(a, b);
+    const float e = __builtin_amdgcn_exp2f(1.4426950408889634f * (float)(n - m));
+    const double r = m + (double)(0.6931471805599453f * __builtin_amdgcn_logf(1.0f + e));
+    return (m == -INFINITY) ? -INFINITY : r;
+}
+
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+// max over the 16 lanes of every row, left in all of them (row_ror:8,4,2,1)
+__device__ __forceinline__ unsigned row_allmax(unsigned v) {
+    unsigned x = dpp_u32<0x128>(v); v = v > x ? v : x;
+    x = dpp_u32<0x124>(v); v = v > x ? v : x;
+    x = dpp_u32<0x122>(v); v = v > x ? v : x;
+    x = dpp_u32<0x121>(v); v = v > x ? v : x;
+    return v;
+}
+__device__ __forceinline__ unsigned wave_allmax(unsigned v) {
+    v = row_allmax(v);
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+
+#define SB_CE(a, b) { const unsigned long long x_ = k[a], y_ = k[b]; const bool sw_ = x_ < y_; k[a] = sw_ ? y_ : x_; k[b] = sw_ ? x_ : y_; }
+
+__global__ __launch_bounds__(64) void beam_small_kernel(
+    const float* __restrict__ lp, long long stride_t, long long stride_b, const int32_t* __restrict__ lengths,
+    int T, int V, int K, int blank, int collapse, int32_t* __restrict__ out_tokens, int32_t* __restrict__ out_len,
+    double* __restrict__ out_score) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* table = reinterpret_cast<unsigned*>(smem);
+    float* frames = reinterpret_cast<float*>(smem + LDS_TABLE);
+    unsigned long long* lst = reinterpret_cast<unsigned long long*>(smem + LDS_TABLE + LDS_FRAMES);
+    unsigned* mm = reinterpret_cast<unsigned*>(smem + LDS_TABLE + LDS_FRAMES + LDS_LIST);
+    const int b = blockIdx.x, lane = threadIdx.x, q = lane >> 4, j = lane & 15;
+    int Tb = lengths ? lengths[b] : T; Tb = Tb < 0 ? 0 : (Tb > T ? T : Tb);
+
+    for (int i = lane; i < H / 4; i += 64) reinterpret_cast<uint4*>(table)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    // entry state, replicated per row
+    double pb = (j == 0) ? 0.0 : -INFINITY, pnb = -INFINITY, tot = (j == 0) ? 0.0 : -INFINITY;
+    unsigned id = (j == 0) ? ROOT : BAD_ID, par = NONE;
+    int last = -1;
+    int nb = 1, root_pos = 0;
+
+    const float* base = lp + (long long)b * stride_b;
+    const int lsym = lane & 31, lhalf = lane >> 5;
+    float pre[16];
+    auto issue = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = t0 + 2 * i + lhalf;
+            pre[i] = (lsym < V && t < Tb) ? base[(long long)t * stride_t + lsym] : -INFINITY;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) frames[buf * (CH * V_MAX) + (2 * i + lhalf) * V_MAX + lsym] = pre[i];
+    };
+    issue(0); commit(0); issue(CH);
+    __syncthreads();
+
+    for (int t = 0; t < Tb; ++t) {
+        if ((t & (CH - 1)) == 0 && t > 0) {          // chunk boundary: the next chunk's rows have long arrived
+            commit((t >> 5) & 1);
+            issue(t + CH);
+            __syncthreads();
+        }
+        const float* fr = frames + ((t >> 5) & 1) * (CH * V_MAX) + (t & (CH - 1)) * V_MAX;
+        const float4 fa = *reinterpret_cast<const float4*>(fr + 8 * q), fc = *reinterpret_cast<const float4*>(fr + 8 * q + 4);
+        const float lpv[8] = {fa.x, fa.y, fa.z, fa.w, fc.x, fc.y, fc.z, fc.w};
+        const float lp_bl = fr[blank];
+        const float lp_la = fr[last >= 0 ? last : 0];
+
+        // ---- where is my parent, which of my children are in the beam ----
+        int pidx = -1;
+        if (j < nb) {
+            if (par == ROOT) pidx = root_pos;
+            else if (par != NONE) pidx = (int)((table[par] >> 25) & 31u) - 1;
+        }
+        if (lane < 16) mm[lane] = 0u;
+        __syncthreads();
+        if (lane < nb && pidx >= 0) atomicOr(&mm[pidx], 1u << last);
+        __syncthreads();
+        const unsigned mmask = mm[j];
+
+        const int src = pidx >= 0 ? pidx : 0;
+        const double pb_i = __shfl(pb, src, 16), tot_i = __shfl(tot, src, 16);
+        const int last_i = __shfl(last, src, 16);
+
+        // ---- stay candidate of entry j (:78-82, :90-96 merged, :103-106) ----
+        const double npb = tot + (double)lp_bl;
+        const bool has_last = last >= 0, has_par = pidx >= 0;
+        const double dla = (double)lp_la;
+        const double own = has_last ? pnb + dla : -INFINITY;                                    // repeat of the last symbol
+        const double ext = (has_last && has_par) ? ((last_i == last) ? pb_i : tot_i) + dla : -INFINITY;   // parent i extended by it
+        const double npnb = lse2f(ext, own);
+        const unsigned lbits = (unsigned)(has_last ? last : 0) << 5;
+        const unsigned t_bl = ((unsigned)blank << 5) | ((unsigned)j << 1);
+        const unsigned t_own = has_last ? (lbits | ((unsigned)j << 1) | 1u) : 0xFFFFu;
+        const unsigned t_e = (has_last && has_par) ? (lbits | ((unsigned)pidx << 1)) : 0xFFFFu;
+        unsigned tie = t_bl < t_own ? t_bl : t_own;
+        tie = tie < t_e ? tie : t_e;
+        const double sstay = lse2f(npb, npnb);
+
+        // ---- the 8 candidates of this lane as keys ----
+        const double tot0 = __shfl(tot, 0, 64);
+        const double ref = (tot0 == -INFINITY) ? 0.0 : tot0;
+        unsigned long long k[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int s = 8 * q + i;
+            const bool is_bl = (s == blank);
+            const bool alive = (j < nb) && (s < V) && (is_bl || !((mmask >> s) & 1u));
+            const double sx = ((s == last) ? pb : tot) + (double)lpv[i];
+            const double sc = is_bl ? sstay : sx;
+            const unsigned tk = is_bl ? tie : (((unsigned)s << 5) | ((unsigned)j << 1));
+            const long long bits = __double_as_longlong(sc - ref);
+            unsigned long long key = (unsigned long long)bits ^ ((unsigned long long)(bits >> 63) | 0x8000000000000000ull);
+            key = (key & ~0x1FFFFull) | ((unsigned long long)(0x3FFu - tk) << 7) | ((unsigned long long)i << 4) | (unsigned long long)j;
+            k[i] = alive ? key : 0ull;
+        }
+        // descending 8-input sorting network (19 exchanges)
+        SB_CE(0, 1) SB_CE(2, 3) SB_CE(4, 5) SB_CE(6, 7)
+        SB_CE(0, 2) SB_CE(1, 3) SB_CE(4, 6) SB_CE(5, 7)
+        SB_CE(1, 2) SB_CE(5, 6) SB_CE(0, 4) SB_CE(3, 7)
+        SB_CE(1, 5) SB_CE(2, 6)
+        SB_CE(1, 4) SB_CE(3, 6)
+        SB_CE(2, 4) SB_CE(3, 5)
+        SB_CE(3, 4)
+#pragma unroll
+        for (int d = 0; d < 6; ++d) lst[d * 64 + lane] = k[d + 2];
+        unsigned long long head = k[0], next = k[1];
+        int ptr = 0;
+
+        // ---- K rounds: pop the winners in rank order ----
+        unsigned packed = 0u;
+        int nnew = 0;
+        for (int r = 0; r < K; ++r) {
+            const unsigned hh = (unsigned)(head >> 32);
+            const unsigned smax = wave_allmax(hh);
+            if (smax == 0u) break;
+            unsigned long long m = __ballot(hh == smax);
+            if (__popcll(m) != 1) {
+                const unsigned ll = (hh == smax) ? (unsigned)head : 0u;
+                const unsigned smaxlo = wave_allmax(ll);
+                m = __ballot(hh == smax && (unsigned)head == smaxlo);
+            }
+            const int wl = __ffsll((long long)m) - 1;
+            const unsigned wlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)head, wl);
+            const unsigned pk = ((unsigned)(wl >> 4) << 7) | (wlo & 0x7Fu);
+            if (j == r) packed = pk;
+            if (lane == wl) {
+                head = next;
+                next = (ptr < 6) ? lst[ptr * 64 + lane] : 0ull;
+                ++ptr;
+            }
+            ++nnew;
+        }
+
+        // ---- the new beam: entry r <- winner r ----
+        const int pj = (int)(packed & 15u), slot = (int)((packed >> 4) & 7u), pq = (int)(packed >> 7);
+        const int s = 8 * pq + slot;
+        const bool valid = j < nnew;
+        const bool stay = (s == blank);
+        const double g_tot = __shfl(tot, pj, 16), g_pb = __shfl(pb, pj, 16);
+        const double g_npb = __shfl(npb, pj, 16), g_npnb = __shfl(npnb, pj, 16), g_sstay = __shfl(sstay, pj, 16);
+        const unsigned g_id = (unsigned)__shfl((int)id, pj, 16), g_par = (unsigned)__shfl((int)par, pj, 16);
+        const int g_last = __shfl(last, pj, 16);
+        const float lps = fr[valid ? s : 0];
+
+        // beam-position bits of the outgoing entries are cleared before the incoming ones are set
+        if (lane < nb && id != ROOT) atomicAnd(&table[id], KEYMASK);
+        unsigned n_id = BAD_ID;
+        if (lane < 16 && valid) {
+            if (stay) n_id = g_id;
+            else {
+                // canonical node of (parent id, symbol): find, else insert
+                const unsigned key = ((g_id << 8) | (unsigned)s) + 1u;
+                unsigned h = (key * 2654435761u) >> 17;
+                for (int guard = 0; guard < H; ++guard) {
+                    const unsigned v = table[h];
+                    if ((v & KEYMASK) == key) { n_id = h; break; }
+                    if (v == 0u) {
+                        const unsigned old = atomicCAS(&table[h], 0u, key);
+                        if (old == 0u || (old & KEYMASK) == key) { n_id = h; break; }
+                    }
+                    h = (h + 1u) & (unsigned)(H - 1);
+                }
+            }
+        }
+        n_id = (unsigned)__shfl((int)n_id, j, 64);
+        if (lane < 16 && valid && n_id != ROOT && n_id != BAD_ID) atomicOr(&table[n_id], (unsigned)(lane + 1) << 25);
+        const unsigned long long rootm = __ballot(lane < 16 && valid && n_id == ROOT);
+        root_pos = rootm ? (__ffsll((long long)rootm) - 1) : -1;
+
+        if (valid) {
+            if (stay) { pb = g_npb; pnb = g_npnb; tot = g_sstay; last = g_last; par = g_par; }
+            else {
+                pb = -INFINITY;
+                pnb = ((s == g_last) ? g_pb : g_tot) + (double)lps;
+                tot = pnb; last = s; par = g_id;
+            }
+            id = n_id;
+        } else { pb = pnb = tot = -INFINITY; last = -1; par = NONE; id = BAD_ID; }
+        nb = nnew;
+        __syncthreads();
+    }
+
+    // ---- result: ancestors of the best entry, in order, optionally through collapse_fn ----
+    __syncthreads();
+    unsigned short* tmp = reinterpret_cast<unsigned short*>(frames);      // up to 4096 tokens: T <= MAX_NODES / beam
+    unsigned cur = (unsigned)__builtin_amdgcn_readlane((int)id, 0);
+    int n = 0;
+    if (nb > 0) {
+        while (cur != ROOT && cur < (unsigned)H && n < T) {
+            const unsigned v = (table[cur] & KEYMASK) - 1u;
+            if (lane == 0) tmp[n] = (unsigned short)(v & 255u);
+            ++n;
+            cur = v >> 8;
+        }
+    }
+    __syncthreads();
+    int32_t* o = out_tokens + (size_t)b * T;
+    int outn = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        int tok = 0; bool keep = false;
+        if (i < n) {
+            tok = tmp[n - 1 - i];
+            keep = !collapse || i == 0 || tok != (int)tmp[n - i];
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) o[outn + __popcll(m & ((1ull << lane) - 1ull))] = tok;
+        outn += __popcll(m);
+    }
+    if (lane == 0) {
+        out_len[b] = outn;
+        const double t0 = __shfl(tot, 0, 64);
+        out_score[b] = (Tb > 0) ? -t0 : -0.0;
+    }
+}
+#undef SB_CE
+}  // namespace sb
+
 }  // namespace
 
 extern "C" size_t pgasr_beam_workspace_bytes(int T, int B, int V, int beam) {
@@ -285,7 +576,7 @@ extern "C" size_t pgasr_beam_workspace_bytes(int T, int B, int V, int beam) {
 }
 
 extern "C" int pgasr_ctc_beam_search(const void* log_probs, int is_f64, long long stride_t, long long stride_b,
-                                     const int32_t* lengths, int T, int B, int V, int beam, int blank,
+                                     const int32_t* lengths, int T, int B, int V, int beam, int blank, int flags,
                                      int32_t* out_tokens, int32_t* out_len, double* out_score,
                                      void* workspace, size_t workspace_bytes, void* stream) {
     if (!log_probs || !out_tokens || !out_len || !out_score) return PGASR_ERR_INVALID_ARG;
@@ -296,17 +587,26 @@ extern "C" int pgasr_ctc_beam_search(const void* log_probs, int is_f64, long lon
     if (!workspace || workspace_bytes < need) return PGASR_ERR_WORKSPACE;
     if ((long long)T * beam + 1 >= (1ll << 24)) return PGASR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    const int collapse = flags & 1;
+    if (!is_f64 && !(flags & 2) && beam <= sb::K_MAX && V <= sb::V_MAX && (long long)T * beam <= sb::MAX_NODES) {
+        // training path: one wave per utterance, trie and candidate lists in LDS, no workspace traffic
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sb::beam_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb::LDS_BYTES);
+        PGASR_LAUNCH_KERNEL(sb::beam_small_kernel, dim3(B), dim3(64), sb::LDS_BYTES, st, (const float*)log_probs, stride_t, stride_b,
+                           lengths, T, V, beam, blank, collapse, out_tokens, out_len, out_score);
+        PGASR_CHECK_LAUNCH();
+        return PGASR_OK;
+    }
     if (hipMemsetAsync(ws.table, 0, (size_t)B * ws.H * sizeof(unsigned long long), st) != hipSuccess) return PGASR_ERR_LAUNCH;
     const size_t lds = beam_lds_bytes(beam, V);
     if (lds > 160 * 1024) return PGASR_ERR_UNSUPPORTED;
     if (is_f64) {   // exact path: fp64 transcendentals (drop-in CTCDecoder.decode)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&beam_search_kernel<double, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         PGASR_LAUNCH_KERNEL((beam_search_kernel<double, false>), dim3(B), dim3(BEAM_THREADS), lds, st, (const double*)log_probs,
-                           stride_t, stride_b, lengths, T, V, beam, blank, ws, out_tokens, out_len, out_score);
+                           stride_t, stride_b, lengths, T, V, beam, blank, collapse, ws, out_tokens, out_len, out_score);
     } else {        // fp32 device log-probs: fast transcendentals
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&beam_search_kernel<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         PGASR_LAUNCH_KERNEL((beam_search_kernel<float, true>), dim3(B), dim3(BEAM_THREADS), lds, st, (const float*)log_probs,
-                           stride_t, stride_b, lengths, T, V, beam, blank, ws, out_tokens, out_len, out_score);
+                           stride_t, stride_b, lengths, T, V, beam, blank, collapse, ws, out_tokens, out_len, out_score);
     }
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;

@@ -1134,6 +1134,18 @@ extern "C" int pgasr_lstm_error_offset(int B, int backward, size_t* offset) {
     return PGASR_OK;
 }
 
+// Synchronous check: waits for `stream`, reads the workspace's sticky error word and turns it into a status.
+extern "C" int pgasr_lstm_status(const void* workspace, size_t workspace_bytes, int B, int backward, void* stream) {
+    if (!workspace || B <= 0) return PGASR_ERR_INVALID_ARG;
+    const WsLayout l = lstm_ws_layout(B, backward != 0);
+    if (workspace_bytes < l.total) return PGASR_ERR_WORKSPACE;
+    int word = 0;
+    if (hipMemcpyAsync(&word, (const char*)workspace + l.err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
+        return PGASR_ERR_LAUNCH;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return PGASR_ERR_LAUNCH;
+    return word != 0 ? PGASR_ERR_TIMEOUT : PGASR_OK;
+}
+
 extern "C" int pgasr_lstm_busy_offset(int B, int backward, size_t* offset) {
     if (!offset || B <= 0) return PGASR_ERR_INVALID_ARG;
     *offset = lstm_ws_layout(B, backward != 0).err + 64;

@@ -47,7 +47,11 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, unsigned long long n,
                                                    float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
-                                                   float weight_decay) {
+                                                   float weight_decay, const int32_t* __restrict__ guard0,
+                                                   const int32_t* __restrict__ guard1) {
+    // guard words (the sticky error words of the step's sweep workspaces): a sweep that gave up on a bounded wait left
+    // invalid gradients behind -- the update is skipped, parameters and moments stay as they were (uniform branch)
+    if ((guard0 && *guard0 != 0) || (guard1 && *guard1 != 0)) return;
     // torch.optim.Adam semantics: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
     // p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
     const float step = lr / bc1;
@@ -80,7 +84,40 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// Batch hand-over (model.py:227-230, `.to(device)`): a few workgroups stream a pinned, device-mapped HOST buffer into
+// HBM with 16-byte loads, 8 in flight per lane.  Unlike hipMemcpyAsync (measured here: the call returns only when the
+// DMA has run, so a copy queued behind an event costs the host its lead over the GPU and every launch latency of the
+// next step is exposed: 9.8 -> 13.9 ms per step) the launch is asynchronous, and on a stream of its own it runs beside
+// the step on CUs the sweeps leave idle.
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_copy_kernel(const v4u* __restrict__ src, v4u* __restrict__ dst,
+                                                          unsigned long long n16, const unsigned char* __restrict__ src_tail,
+                                                          unsigned char* __restrict__ dst_tail, unsigned tail) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+    unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        v4u v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(src + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[i + k * stride] = v[k];
+    }
+    for (; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+    if (blockIdx.x == 0 && threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
 }  // namespace
+
+extern "C" int pgasr_stream_copy(const void* src, void* dst, unsigned long long bytes, int workgroups, void* stream) {
+    if (!src || !dst || bytes == 0 || workgroups <= 0 || workgroups > 1024) return PGASR_ERR_INVALID_ARG;
+    if ((((size_t)src) | ((size_t)dst)) & 15) return PGASR_ERR_INVALID_ARG;
+    const unsigned long long n16 = bytes / 16;
+    const unsigned tail = (unsigned)(bytes % 16);
+    PGASR_LAUNCH_KERNEL(stream_copy_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const v4u*)src, (v4u*)dst, n16,
+                       (const unsigned char*)src + n16 * 16, (unsigned char*)dst + n16 * 16, tail);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
 
 extern "C" int pgasr_dropout(const float* x, float* y, unsigned long long n, float p, uint64_t seed, uint32_t offset,
                              const float* dact_y, float slope, void* stream) {
@@ -97,16 +134,18 @@ extern "C" int pgasr_dropout(const float* x, float* y, unsigned long long n, flo
 }
 
 extern "C" int pgasr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, unsigned long long n,
-                               int step, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+                               int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                               const int32_t* guard0, const int32_t* guard1, void* stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n == 0 || step < 1) return PGASR_ERR_INVALID_ARG;
     if ((((size_t)param) | ((size_t)grad) | ((size_t)exp_avg) | ((size_t)exp_avg_sq)) & 15) return PGASR_ERR_INVALID_ARG;
+    if ((((size_t)guard0) | ((size_t)guard1)) & 3) return PGASR_ERR_INVALID_ARG;
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     unsigned blocks = (unsigned)((n / 4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
     PGASR_LAUNCH_KERNEL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
-                       lr, beta1, beta2, eps, bc1, bc2_sqrt, weight_decay);
+                       lr, beta1, beta2, eps, bc1, bc2_sqrt, weight_decay, guard0, guard1);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }

@@ -113,9 +113,14 @@ class InstNormAffineFn(torch.autograd.Function):
         ctx.consumer_applies_dact = bool(consumer_applies_dact)
         mean, rstd = hipops.instnorm_stats(x, 1e-5)
         y = torch.empty(T, B, N, dtype=torch.float32, device=x.device)
+        # exact fp32 MFMA (precision 0), not the bf16x3 split: leaky_relu' is a step function of this product's SIGN, and a
+        # pre-activation that is zero to 1e-5 relative (the split's error) flips it -- measured at the headline shape:
+        # ~160 of 16 M pre-activations changed side against the fp32 CPU path, each one scaling a summand of the
+        # input layer's weight/bias gradient by 100 (1e-2 max-norm error on those two tensors under a REINFORCE
+        # gradient, 6e-4 under CTC alone).  K = F is tiny: the exact product costs ~10 us more per step.
         hipops.gemm(x, weight, y, M=T, N=N, K=F, transA=True, transB=True, lda=T, ldb=F, ldc=B * N,
                     strideA=F * T, strideB=0, strideC=N, batch=B, bias=bias, act=1, slope=LEAKY_SLOPE,
-                    norm_operand=1, shift=mean, scale=rstd)
+                    norm_operand=1, shift=mean, scale=rstd, precision=0)
         ctx.save_for_backward(x, weight, mean, rstd, y)
         return y
 

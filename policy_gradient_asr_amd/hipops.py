@@ -180,13 +180,20 @@ def frame_argmax_sample(scores, seed=0, offset=0, want_greedy=True, want_sample=
     return g, s
 
 
-def ctc_collapse(paths, lengths, blank=0):
-    """paths (P,T,B) int32 -> tokens (P,B,T) int32, token_lengths (P,B) int32."""
+def ctc_collapse(paths, lengths, blank=0, out=None):
+    """paths (P,T,B) int32 -> tokens (P,B,T) int32, token_lengths (P,B) int32.
+    out = (tokens, token_lengths) to write into (contiguous, zero-filled tokens)."""
     lib = _lib.load()
     _req(paths, torch.int32, "paths"); _req(lengths, torch.int32, "lengths")
     P, T, B = paths.shape
-    tokens = torch.zeros(P, B, T, dtype=torch.int32, device=paths.device)
-    tl = torch.empty(P, B, dtype=torch.int32, device=paths.device)
+    if out is not None:
+        tokens, tl = out
+        _req(tokens, torch.int32, "out tokens"); _req(tl, torch.int32, "out lengths")
+        if tokens.numel() != P * B * T or tl.numel() != P * B:
+            raise _lib.PgasrError("ctc_collapse: out tensors must hold (P,B,T) and (P,B) int32")
+    else:
+        tokens = torch.zeros(P, B, T, dtype=torch.int32, device=paths.device)
+        tl = torch.empty(P, B, dtype=torch.int32, device=paths.device)
     st = lib.pgasr_ctc_collapse(_p(paths), _p(lengths), P, T, B, blank, _p(tokens), _p(tl), _stream())
     _lib.check(st, "pgasr_ctc_collapse")
     return tokens, tl
@@ -442,22 +449,40 @@ def lstm_check_error(ws, B, backward):
 
 
 def lstm_assert_no_timeouts():
-    """Host-side check of EVERY sweep workspace this process has used (synchronises): a persistent sweep that gave up
-    on a bounded wait -- its cluster, its helpers or the GEMM feeding it never showed up -- leaves its error word set
-    and its results are invalid.  Cheap enough for once per epoch / once per benchmark run."""
-    torch.cuda.synchronize()
-    bad = [key[0] for key, ws in _ws_cache.items()
-           if key[0].startswith("lstm") and int(ws[:4].view(torch.int32).item()) != 0]
-    if bad:
-        raise _lib.PgasrError(f"persistent LSTM sweep timed out (status 5) in workspace(s) {sorted(set(bad))}")
+    """Host-side check of EVERY sweep workspace this process has used (synchronises the current stream): a persistent
+    sweep that gave up on a bounded wait -- its cluster, its helpers or the GEMM feeding it never showed up -- leaves
+    its sticky error word set and its results are invalid.  ``pgasr_lstm_status`` turns the word into
+    PGASR_ERR_TIMEOUT, which is raised here.  Call it wherever the host synchronises anyway (the loss print every
+    ``log_every`` steps, before a checkpoint is written, at the end of a benchmark); between two calls the guarded
+    Adam (``lstm_error_words``) keeps invalid gradients away from the parameters."""
+    lib = _lib.load()
+    for key, ws in list(_ws_cache.items()):
+        if not key[0].startswith("lstm"):
+            continue
+        st = lib.pgasr_lstm_status(ws.data_ptr(), ws.numel(), 1, int(key[0] == "lstm_bwd"), _stream())
+        if st == _lib.TIMEOUT:
+            raise _lib.PgasrError(f"persistent LSTM sweep timed out (status {st}: {lib.pgasr_status_string(st).decode()}) "
+                                  f"in workspace {key[0]!r}; its outputs and every gradient since are invalid")
+        _lib.check(st, "pgasr_lstm_status")
+
+
+def lstm_error_words(device):
+    """Device addresses of the sticky error words of the sweep workspaces used on the CURRENT stream (at most two:
+    forward, backward) -- the guards of ``adam_step``."""
+    cur = torch.cuda.current_stream().cuda_stream
+    return [ws.data_ptr() for key, ws in _ws_cache.items()
+            if key[0].startswith("lstm") and key[1] == device and key[2] == cur][:2]
 
 
 # ------------------------------------------------------------------------------------------
 # prefix beam search
 # ------------------------------------------------------------------------------------------
-def ctc_beam_search(log_probs, lengths=None, beam=5, blank=0):
+def ctc_beam_search(log_probs, lengths=None, beam=5, blank=0, collapse=False, out=None, generic=False):
     """log_probs (T,B,V) fp32 or fp64 natural-log probabilities on the GPU.
-    Returns (tokens (B,T) int32, token_lengths (B) int32, score (B) float64 = -log p)."""
+    Returns (tokens (B,T) int32, token_lengths (B) int32, score (B) float64 = -log p).
+    collapse: the returned tokens have gone through collapse_fn (adjacent duplicates removed, CTCdecoder.py:119-131),
+    the form policy_grad.py:8 scores.  out = (tokens, token_lengths) to write into (tokens zero-filled).
+    generic: never take the single-wave small-beam kernel (testing)."""
     lib = _lib.load()
     if not log_probs.is_cuda or log_probs.dtype not in (torch.float32, torch.float64):
         raise _lib.PgasrError("log_probs must be a float32/float64 GPU tensor")
@@ -467,12 +492,19 @@ def ctc_beam_search(log_probs, lengths=None, beam=5, blank=0):
     _req(lengths, torch.int32, "lengths")
     nbytes = lib.pgasr_beam_workspace_bytes(T, B, V, beam)
     ws = _workspace(nbytes, log_probs.device, "beam")
-    tokens = torch.zeros(B, T, dtype=torch.int32, device=log_probs.device)
-    tl = torch.empty(B, dtype=torch.int32, device=log_probs.device)
+    if out is not None:
+        tokens, tl = out
+        _req(tokens, torch.int32, "out tokens"); _req(tl, torch.int32, "out lengths")
+        if tokens.numel() != B * T or tl.numel() != B:
+            raise _lib.PgasrError("ctc_beam_search: out tensors must hold (B,T) and (B) int32")
+    else:
+        tokens = torch.zeros(B, T, dtype=torch.int32, device=log_probs.device)
+        tl = torch.empty(B, dtype=torch.int32, device=log_probs.device)
     score = torch.empty(B, dtype=torch.float64, device=log_probs.device)
-    st = lib.pgasr_ctc_beam_search(_p(log_probs), int(log_probs.dtype == torch.float64), log_probs.stride(0),
-                                   log_probs.stride(1), _p(lengths), T, B, V, int(beam), int(blank),
-                                   _p(tokens), _p(tl), _p(score), _p(ws), ws.numel(), _stream())
+    with _timed("beam_search"):
+        st = lib.pgasr_ctc_beam_search(_p(log_probs), int(log_probs.dtype == torch.float64), log_probs.stride(0),
+                                       log_probs.stride(1), _p(lengths), T, B, V, int(beam), int(blank), int(bool(collapse)) | (2 if generic else 0),
+                                       _p(tokens), _p(tl), _p(score), _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_ctc_beam_search")
     return tokens, tl, score
 
@@ -493,13 +525,30 @@ def dropout(x, p, seed, offset, out=None, dact_y=None, slope=0.01):
     return out
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+def stream_copy(dst, src, workgroups=8):
+    """dst (GPU tensor) <- src: a GPU tensor or a PINNED host tensor (mapped into the device's address space), same
+    dtype and element count, both contiguous.  A kernel on the current stream; never blocks the host."""
+    lib = _lib.load()
+    if not dst.is_cuda or not dst.is_contiguous() or not src.is_contiguous() or dst.dtype != src.dtype or dst.numel() != src.numel():
+        raise _lib.PgasrError("stream_copy: contiguous tensors of one dtype and size, destination on the GPU")
+    if not src.is_cuda and not src.is_pinned():
+        raise _lib.PgasrError("stream_copy: a host source must be pinned (device-mapped) memory")
+    nbytes = dst.numel() * dst.element_size()
+    if nbytes == 0:
+        return dst
+    _lib.check(lib.pgasr_stream_copy(src.data_ptr(), dst.data_ptr(), nbytes, int(workgroups), _stream()), "pgasr_stream_copy")
+    return dst
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, guards=()):
+    """guards: up to two device addresses of int32 words (``lstm_error_words``); the update is skipped while one is set."""
     lib = _lib.load()
     for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         _req(t, torch.float32, nm)
+    g = list(guards)[:2] + [0, 0]
     _lib.check(lib.pgasr_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), int(step),
                                    float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
-                                   _stream()), "pgasr_adam_step")
+                                   g[0], g[1], _stream()), "pgasr_adam_step")
 
 
 def lstm_busy_ptr(T, B, backward, device, stream=None):
@@ -518,6 +567,7 @@ def lstm_busy_ptr(T, B, backward, device, stream=None):
 
 
 _concurrent = {}
+STRICT_CONCURRENCY = False   # bench.py: raise instead of quietly running the (slower) sequential order
 
 
 def streams_concurrent(other):
@@ -535,6 +585,10 @@ def streams_concurrent(other):
             words[0:1].fill_(1)
         torch.cuda.synchronize()
         _concurrent[key] = bool(int(words[1].item()) == 1)
+        if not _concurrent[key] and STRICT_CONCURRENCY:
+            raise _lib.PgasrError("kernels of different streams do not run concurrently here (serialising profiler / launch-blocking "
+                                  "mode / one hardware queue): the feed-ahead GEMMs would fall back to the sequential order; set "
+                                  "PGASR_ALLOW_SEQUENTIAL=1 to benchmark that order knowingly")
         if not _concurrent[key]:
             import warnings
             warnings.warn("policy_gradient_asr_amd: kernels of different streams do not run concurrently here "

@@ -32,13 +32,18 @@ class PGCTCLossFn(torch.autograd.Function):
     """loss = (1/Bg) sum_b [ nll_b / max(L_b,1)  -  lam * (R_s,b - R_g,b) * sum_{t<T_b} log p(pi_t,b) ]
 
     pi ~ softmax(logits) per frame (Philox, seed-addressable), R = -ED(y, collapse(path)) / max(L,1)
-    for the sampled (R_s) and greedy (R_g, baseline) paths; Bg = global batch (all ranks).
+    for the sampled (R_s) path and for the baseline hypothesis (R_g): the greedy best path (beam = 0), or -- the
+    reference's own reward definition, policy_grad.py:6-8 -- the prefix-beam-search hypothesis of width ``beam``
+    after collapse_fn.  Bg = global batch (all ranks).  The reward is the utterance-level R = -ED / |y|: the
+    reference's per-step r_t (policy_grad.py:10-15) telescope to |y| - ED(y, yhat), i.e. to the
+    same R up to the constant |y| that the baseline subtracts; the per-t values themselves are available from
+    policy_grad.rewards_all_t, and the gradient uses their sum (one coefficient per utterance).
     Returns (loss, stats) where stats = (nll (B), R_s (B), R_g (B)) detached."""
 
     _lattice_streams = {}      # one lattice stream per calling stream
 
     @staticmethod
-    def forward(ctx, logits, in_len, targets, tg_len, lam, seed, offset, global_batch, blank):
+    def forward(ctx, logits, in_len, targets, tg_len, lam, seed, offset, global_batch, blank, beam=0):
         T, B, V = logits.shape
         dev = logits.device
         lp = hipops.log_softmax_rows(logits.contiguous())
@@ -51,9 +56,17 @@ class PGCTCLossFn(torch.autograd.Function):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             nll, lattice = hipops.ctc_lattice(lp, targets, in_len, tg_len, blank=blank)
-        greedy, sample = hipops.frame_argmax_sample(lp, seed=seed, offset=offset)
-        paths = torch.stack((greedy, sample), dim=0)                          # (2,T,B)
-        tokens, tok_len = hipops.ctc_collapse(paths, in_len, blank=blank)     # (2,B,T), (2,B)
+        if beam > 0:
+            # baseline hypothesis = prefix beam search + collapse_fn (policy_grad.py:6-8), rows [0] of the pair buffers
+            _, sample = hipops.frame_argmax_sample(lp, seed=seed, offset=offset, want_greedy=False)
+            tokens = torch.zeros(2, B, T, dtype=torch.int32, device=dev)
+            tok_len = torch.empty(2, B, dtype=torch.int32, device=dev)
+            hipops.ctc_beam_search(lp, in_len, beam=beam, blank=blank, collapse=True, out=(tokens[0], tok_len[0]))
+            hipops.ctc_collapse(sample[None], in_len, blank=blank, out=(tokens[1:], tok_len[1:]))
+        else:
+            greedy, sample = hipops.frame_argmax_sample(lp, seed=seed, offset=offset)
+            paths = torch.stack((greedy, sample), dim=0)                          # (2,T,B)
+            tokens, tok_len = hipops.ctc_collapse(paths, in_len, blank=blank)     # (2,B,T), (2,B)
         dist = hipops.edit_distance(targets.repeat(2, 1), tg_len.repeat(2), tokens.view(2 * B, T), tok_len.view(2 * B))
         R_g, R_s, coef, utt_scale = hipops.pg_rewards(dist, tg_len, lam, 1.0 / float(global_batch))
         main.wait_stream(side)
@@ -68,13 +81,14 @@ class PGCTCLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, *unused):
         (grad,) = ctx.saved_tensors
-        return grad * g, None, None, None, None, None, None, None, None
+        return grad * g, None, None, None, None, None, None, None, None, None
 
 
-def pg_ctc_loss(logits, in_len, targets, tg_len, lam=1.0, seed=0, offset=0, global_batch=None, blank=0):
+def pg_ctc_loss(logits, in_len, targets, tg_len, lam=1.0, seed=0, offset=0, global_batch=None, blank=0, beam=0):
+    """beam > 0: the baseline reward comes from the prefix-beam-search hypothesis of that width (see PGCTCLossFn)."""
     B = logits.shape[1]
     return PGCTCLossFn.apply(logits, in_len, targets, tg_len, float(lam), int(seed), int(offset),
-                             int(global_batch or B), int(blank))
+                             int(global_batch or B), int(blank), int(beam))
 
 
 class CTCLoss(nn.Module):

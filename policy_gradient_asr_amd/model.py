@@ -181,6 +181,13 @@ def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset
         st = torch.load(ckpt, map_location=dev)
         model.load_state_dict(st["model"])
         trainer.exp_avg.copy_(st["exp_avg"]); trainer.exp_avg_sq.copy_(st["exp_avg_sq"]); trainer.nstep = st["nstep"]
+        # the dropout masks are functions of (seed, call counter): restore both, or a resumed run replays the first
+        # epoch's masks and differs from an uninterrupted one
+        model.encoder._drop_calls = st.get("drop_calls", 0)
+        model.encoder.dropout_seed = st.get("dropout_seed", model.encoder.dropout_seed)
+        for k, want in (("lr", lr), ("lam", lam)):
+            if k in st and st[k] != want:
+                print("Warning: resuming with {}={} but the checkpoint was written with {}".format(k, want, st[k]))
         losses, val_losses, best, start_epoch = st["losses"], st["val_losses"], st["best"], st["epoch"] + 1
         print("Resumed from epoch", st["epoch"])
 
@@ -199,9 +206,11 @@ def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset
             loss = trainer.step(*_to_device(batch, dev))
             acc += loss
             if log_every and step % log_every == 0:
-                print("Step {}/{}. Loss: {:>4f}".format(step, len(loader), float(loss)))
+                val = float(loss)                      # the host synchronises here anyway: check the sweeps' error words
+                hipops.lstm_assert_no_timeouts()       # (until then the guarded Adam has skipped every invalid update)
+                print("Step {}/{}. Loss: {:>4f}".format(step, len(loader), val))
         losses.append(float(acc) / max(len(loader), 1))
-        hipops.lstm_assert_no_timeouts()          # a sweep that gave up on a wait must not pass silently
+        hipops.lstm_assert_no_timeouts()          # .. and before anything of this epoch is written to disk
         np.save(os.path.join(model_path, "train_loss.npy"), np.array(losses))
         print("Epoch:{}/{} Training loss:{:>4f}".format(epoch, num_epochs, losses[-1]))
 
@@ -227,7 +236,9 @@ def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset
             best = curr
         torch.save(sd, os.path.join(model_path, "model_last.pth"))
         torch.save({"model": sd, "exp_avg": trainer.exp_avg, "exp_avg_sq": trainer.exp_avg_sq, "nstep": trainer.nstep,
-                    "losses": losses, "val_losses": val_losses, "best": best, "epoch": epoch}, ckpt)
+                    "losses": losses, "val_losses": val_losses, "best": best, "epoch": epoch,
+                    "drop_calls": model.encoder._drop_calls, "dropout_seed": model.encoder.dropout_seed,
+                    "lr": lr, "lam": lam}, ckpt)
     return losses, val_losses
 
 

@@ -49,10 +49,11 @@ def test_python_signature_table_matches_header(lib):
 
 def test_abi_version_and_status_strings(lib):
     lib.pgasr_abi_version.restype = ctypes.c_int
-    assert lib.pgasr_abi_version() == 1
+    assert lib.pgasr_abi_version() == 2
     lib.pgasr_status_string.restype = ctypes.c_char_p
     assert lib.pgasr_status_string(0) == b"ok"
     assert b"workspace" in lib.pgasr_status_string(3)
+    assert b"timed out" in lib.pgasr_status_string(5)
 
 
 def test_workspace_query_needs_no_gpu(lib):

@@ -56,6 +56,40 @@ def test_beam_batch_fp32_vs_oracle_and_lengths():
         assert float(score[b]) == pytest.approx(nll, rel=1e-6)
 
 
+@pytest.mark.parametrize("T,B,V,beam,blank", [(1, 3, 29, 16, 0), (8, 4, 29, 5, 0), (50, 6, 29, 16, 0), (200, 5, 29, 16, 0),
+                                               (200, 3, 29, 1, 0), (60, 4, 4, 16, 0), (40, 4, 32, 16, 0), (90, 4, 29, 16, 3),
+                                               (300, 2, 29, 7, 0)])
+def test_small_beam_kernel_vs_oracle_and_generic(T, B, V, beam, blank):
+    """The single-wave training-path search (fp32, beam <= 16, V <= 32) against the fp64 oracle on the SAME fp32
+    log-probs (hypothesis bit-exact, score 1e-6) and against the generic LDS-sort kernel; ragged lengths, peaked and
+    flat frames, exact zeros (log p = -inf), fewer candidates than the beam (V = 4), a non-zero blank."""
+    from policy_gradient_asr_amd import hipops
+    rng = np.random.default_rng(100 * T + V + beam)
+    logits = rng.normal(size=(T, B, V)) * rng.choice([0.3, 2.0, 5.0], size=(T, B, 1))
+    logits[:, :, blank] += 1.5
+    lp = torch.log_softmax(torch.tensor(logits, dtype=torch.float32), 2)
+    if T >= 8:
+        lp[3, 0, 1:3] = -float("inf")                      # zero probabilities
+        lp[5, B - 1, :] = -float("inf"); lp[5, B - 1, min(2, V - 1)] = 0.0
+    lens = np.array([T] + [max(0, T - 7 * b) for b in range(1, B)], dtype=np.int32)
+    lens[-1] = T
+    d_lp, d_len = lp.to(DEV), torch.from_numpy(lens).to(DEV)
+    tok, tl, score = hipops.ctc_beam_search(d_lp, d_len, beam=beam, blank=blank)
+    gtok, gtl, gscore = hipops.ctc_beam_search(d_lp, d_len, beam=beam, blank=blank, generic=True)
+    ctok, ctl, _ = hipops.ctc_beam_search(d_lp, d_len, beam=beam, blank=blank, collapse=True)
+    assert torch.equal(tl, gtl) and torch.equal(tok, gtok)
+    torch.testing.assert_close(score, gscore, rtol=1e-6, atol=1e-6)
+    for b in range(B):
+        n = int(lens[b])
+        want, nll = decode_ref.prefix_beam_search(np.exp(lp[:n, b].double().numpy()), beam_size=beam, blank=blank) if n else ((), 0.0)
+        got = list(tok[b, :tl[b]].cpu().numpy())
+        assert got == list(want), (b, n)
+        assert float(score[b]) == pytest.approx(nll, rel=1e-6, abs=1e-6)
+        dedup = [x for i, x in enumerate(got) if i == 0 or x != got[i - 1]]          # collapse_fn on token ids
+        assert list(ctok[b, :ctl[b]].cpu().numpy()) == dedup
+        assert int(ctok[b, ctl[b]:].abs().sum()) == 0
+
+
 def test_beam_headline_size_properties():
     """T=1000,B=32,beam=16: runs, scores finite and never better than the CTC total."""
     from policy_gradient_asr_amd import hipops
@@ -70,6 +104,21 @@ def test_beam_headline_size_properties():
     for b in (0, 13, 31):
         seq = tok[b, :tl[b]]
         assert ((seq >= 1) & (seq < V)).all()
+    # The single-wave kernel (taken above) against the fp64 oracle on two whole utterances, and against the generic
+    # kernel on all of them.  The two fp32 kernels carry ~1e-7 of transcendental noise per frame in different places, so
+    # a hypothesis may legitimately differ where two candidates are closer than that: scores must agree, and all but a
+    # few hypotheses; flat (untrained-model-like) frames too.
+    for b in (0, 31):
+        want, nll = decode_ref.prefix_beam_search(np.exp(lp[:, b].double().cpu().numpy()), beam_size=16)
+        assert list(tok[b, :tl[b]].cpu().numpy()) == list(want)
+        assert float(score[b]) == pytest.approx(nll, rel=1e-6)
+    flat = torch.log_softmax(torch.randn(T, B, V, generator=g) * 0.05, 2).to(DEV)
+    for x in (lp, flat):
+        a = hipops.ctc_beam_search(x, None, beam=16)
+        c = hipops.ctc_beam_search(x, None, beam=16, generic=True)
+        torch.testing.assert_close(a[2], c[2], rtol=1e-5, atol=1e-4)
+        same = sum(int(a[1][b] == c[1][b] and torch.equal(a[0][b], c[0][b])) for b in range(B))
+        assert same >= B - 3, same
 
 
 def test_collapse_fn_and_greedy(vectors):

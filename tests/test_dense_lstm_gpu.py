@@ -148,6 +148,7 @@ def _lstm_case(T, B, lens, seed, in_dim=512):
     (3, 17, [3] * 9 + [1] * 8),                     # one utterance over a 16-utterance group: a second, nearly empty cluster pair
     (7, 48, [7] * 20 + [4] * 28),                   # three groups = six clusters
     (5, 80, [5] * 50 + [2] * 30),                   # ten clusters: two share an XCD, no room for helper workgroups
+    (6, 128, [6] * 70 + [3] * 40 + [1] * 18),       # the compiled-in limit B = 128: sixteen clusters, two per XCD
 ])
 def test_blstm_layer_vs_torch_cpu(T, B, lens):
     from policy_gradient_asr_amd import functional as Fh
@@ -299,7 +300,7 @@ def test_seq2seq_logprobs_and_grads_vs_oracle():
     assert rel_err(lp.detach().cpu(), lp_ref.detach()) < 1e-3
     for k, v in m.named_parameters():
         rk = k[len("encoder."):] if k.startswith("encoder.") else k
-        assert rel_err(v.grad.cpu(), pr[rk].grad) < 2e-3, k
+        assert rel_err(v.grad.cpu(), pr[rk].grad) < 1e-3, k       # north_star tolerance
 
 
 def test_stream_gate_opens_on_busy_word_or_timeout():

@@ -9,8 +9,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
+export PGASR_ALLOW_SEQUENTIAL=1   # counter passes serialise kernels: the feed-ahead paths fall back to the sequential order (same kernels)
 rm -rf "$O/${TAG}_stats" "$O/${TAG}_fetch" "$O/${TAG}_write"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_stats" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$O/${TAG}_stats.log" 2>&1 &&
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/${TAG}_fetch" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$O/${TAG}_fetch.log" 2>&1 &&
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/${TAG}_write" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$O/${TAG}_write.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_stats" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-parity > "$O/${TAG}_stats.log" 2>&1 &&
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/${TAG}_fetch" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-parity > "$O/${TAG}_fetch.log" 2>&1 &&
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/${TAG}_write" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-parity > "$O/${TAG}_write.log" 2>&1
 echo "profile_round rc=$?"
