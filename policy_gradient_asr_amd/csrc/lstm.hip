@@ -93,13 +93,21 @@ struct LstmArgs {
     const int* lengths;      // [B]
     int T, B, NBG, NCL8;
     int force_mode;          // 0 auto, 1 force write-through (cross-XCD safe), for tests
-    int diag;                // diagnostic timing switches (results invalid): bit0 skip bulk stores, bit1 skip xproj prefetch
+    int diag;                // diagnostic timing switches (results invalid): bit0 skip bulk stores, bit1 skip xproj prefetch,
+                             // bit2 take the first poll as it comes (no tag check), bit3 no exchange loads at all, bit4 no publish
     long long* stamps;       // diagnostic build only (-DPGASR_LSTM_STAMPS)
 };
 
 #ifdef PGASR_LSTM_STAMPS
-#define STAMP(slot) do { if (g == 5 && bg == 0 && dir == 0 && tid == 0) a.stamps[(size_t)step * 8 + (slot)] = clock64(); } while (0)
+// Diagnostic build: wave 0 of every workgroup accumulates, in registers, the cycles between consecutive stamps (segment
+// ending at `slot`); one store per workgroup at the end (member 5 of cluster 0 is read by tools/dev/tools_stamps.py).  No memory
+// traffic in the loop: per-step stores of the stamps sat in front of the wave's next s_waitcnt vmcnt(0) and distorted the picture.
+#define STAMP_DECL long long st_last_ = clock64(); long long st_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(slot) do { if (w == 0) { const long long now_ = clock64(); st_acc_[slot] += now_ - st_last_; st_last_ = now_; } } while (0)
+#define STAMP_FLUSH() do { if (g == 5 && bg == 0 && dir == 0 && tid == 0) { for (int i_ = 0; i_ < 8; ++i_) a.stamps[i_] = st_acc_[i_]; } } while (0)
 #else
+#define STAMP_DECL
+#define STAMP_FLUSH() do { } while (0)
 #define STAMP(slot) do { } while (0)
 #endif
 
@@ -148,6 +156,13 @@ __device__ __forceinline__ void release_xcd(const LstmArgs& a, int g, int tid) {
     }
 }
 
+// Workgroup flags in LDS.  They were `volatile int` reached through generic pointers: hipcc then emits FLAT loads with
+// sc0 sc1 followed by s_waitcnt vmcnt(0) -- in the step loop that was one flat round trip per step on the chain AND a
+// drain of every outstanding global store / LDS-DMA of the loader and storer waves (whose whole point is never to
+// wait for memory).  Relaxed workgroup-scope atomics on plain __shared__ ints compile to ds_read_b32 / ds_write_b32.
+#define LDS_FLAG_GET(var) __hip_atomic_load(&(var), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define LDS_FLAG_SET(var, val) __hip_atomic_store(&(var), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+
 struct SpinGuard {
     unsigned spins = 0; long long t0 = 0;
     // returns false when the wait has lasted longer than SPIN_TIMEOUT_TICKS
@@ -167,27 +182,28 @@ struct SpinGuard {
 // (one L2): payload stores may stay in that L2 (plain stores), which consumers reach with
 // L1-bypassing loads at L2-hit latency.  Otherwise stores are write-through (sc1) so that they
 // reach memory where any XCD sees them.  Placement only selects the faster legal protocol.
-__device__ __forceinline__ bool cluster_same_xcd(const LstmArgs& a, int cl, int g, int tid, volatile int* s_flag,
-                                                 volatile int* s_abort) {
+__device__ __forceinline__ bool cluster_same_xcd(const LstmArgs& a, int cl, int g, int tid, int& s_flag, int& s_abort) {
     if (tid < 64) {
         unsigned* hw = a.hello + (size_t)cl * 16;
         const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xFu;
-        if (tid == 0) __hip_atomic_store(hw + g, 0x100u | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // bits 16..: HW_REG_HW_ID (cu / sh / se of this workgroup) -- diagnostic only (tools/dev/tools_stamps.py)
+        const unsigned hwid = __builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4) & 0xFFFFu;
+        if (tid == 0) __hip_atomic_store(hw + g, 0x100u | xcc | (hwid << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         SpinGuard sg;
         unsigned v = 0x100u | xcc;
         while (true) {
             POLL_FENCE();
             if (tid < 16) v = __hip_atomic_load(hw + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!__any(v == 0u)) break;
-            if (!sg.keep_waiting()) { *s_abort = 1; *a.err = 1; break; }
+            if (!sg.keep_waiting()) { LDS_FLAG_SET(s_abort, 1); *a.err = 1; break; }
         }
         const bool same = !__any((v & 0xFu) != xcc);
-        if (tid == 0) *s_flag = (same && a.force_mode == 0) ? 1 : 0;
+        if (tid == 0) LDS_FLAG_SET(s_flag, (same && a.force_mode == 0) ? 1 : 0);
         // tell overlapped GEMMs which XCD this cluster occupies (a speed hint, released at kernel end)
         if (tid == 0 && g == 0) __hip_atomic_fetch_add(a.busy + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    return *s_flag != 0;
+    return LDS_FLAG_GET(s_flag) != 0;
 }
 
 
@@ -204,7 +220,7 @@ __device__ __forceinline__ bool cluster_same_xcd(const LstmArgs& a, int cl, int 
 //   Placement is verified, not assumed: a helper that finds itself on another XCD than member 0 writes the ring
 //   with write-through stores, and the loaders always read it with L1-bypassing loads.
 __device__ __forceinline__ void helper_loop(const LstmArgs& a, int cl, int dir, int bg, int h, bool backward,
-                                            volatile int* s_flag) {
+                                            int* s_flag) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int T = a.T, B = a.B;
     if (w >= 4) return;      // four waves move the rows (the barriers below count only live waves)
@@ -394,9 +410,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) float4 rg[2][256];                  // results: gate activations
     __shared__ __attribute__((aligned(16))) float rc[2][256];                   //          c_t
     __shared__ __attribute__((aligned(16))) float rh[2][256];                   //          h_t (0 past the length)
-    __shared__ volatile int s_abort;
-    __shared__ volatile int s_same;
-    if (tid == 0) { s_abort = 0; s_same = 0; }
+    __shared__ int s_abort;
+    __shared__ int s_same;
+    if (tid == 0) { LDS_FLAG_SET(s_abort, 0); LDS_FLAG_SET(s_same, 0); }
     __syncthreads();
 
     // weight slices -> registers: tile m (units 4(4g+m)..+3, row = 4*uu+gate), k-steps 2w, 2w+1
@@ -415,11 +431,12 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
     constexpr unsigned SLOT = 32 * 16 * 2 * 16;       // bytes per parity slot (16 KiB)
     unsigned char* xb = a.xbuf + (size_t)cl * (2 * SLOT);
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)(2 * SLOT), 0x00020000);
-    const bool same_xcd = cluster_same_xcd(a, cl, g, tid, &s_same, &s_abort);
+    const bool same_xcd = cluster_same_xcd(a, cl, g, tid, s_same, s_abort);
 
     const int bidx = bg * 16 + pn;
     const int len = (bidx < B) ? a.lengths[bidx] : 0;
     float c = 0.f, h = 0.f;
+    STAMP_DECL;
 
     // ---- loader / storer: lane L serves cells 64k+L (k = 0..3) for 16-byte rows, cells 4L..4L+3 for 4-byte rows
     auto step_t = [&](int s) { return dir ? T - 1 - s : s; };
@@ -437,7 +454,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
         while (true) {
             POLL_FENCE();
             if (__hip_atomic_load(ready + (s % RING_STEPS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(s + 1)) break;
-            if (s_abort || !sgr.keep_waiting()) { s_abort = 1; *a.err = 1; break; }
+            if (LDS_FLAG_GET(s_abort) || !sgr.keep_waiting()) { LDS_FLAG_SET(s_abort, 1); *a.err = 1; break; }
             __builtin_amdgcn_s_sleep(1);
         }
     };
@@ -476,21 +493,34 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
             *reinterpret_cast<float4*>(a.out + ((size_t)t * B + b) * (2 * HID) + dir * HID + u0) = *reinterpret_cast<const float4*>(&rh[par][cell0]);
         }
     };
+    // Three role-specialised loops with ONE LDS barrier per step each (the counts must match).  One shared loop with
+    // `if (w == ...)` regions cost the compute waves a dozen exec-mask branches per step: a taken branch refills the
+    // instruction buffer, and at ~2700 cycles per step those bubbles were measurable.  Abort protocol: every wave reads
+    // the flag right behind the barrier (a wave can only set it after seconds of spinning, so all see the same value)
+    // and leaves at the end of that step.
     if (w == LOADER_WAVE) {
         for (int s = 0; s < FWD_LEAD; ++s) loader_issue(s);
-    }
-
-    {
         for (int step = 0; step < T; ++step) {
-            const int t = step_t(step);
-            if (w == LOADER_WAVE) {
-                loader_issue(step + FWD_LEAD);
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * FWD_LEAD) : "memory");   // this step's rows have landed
-            }
-            if (g == 0 && tid == 0)     // paces the helpers (which may sit on another XCD: agent-scope store)
+            loader_issue(step + FWD_LEAD);
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * FWD_LEAD) : "memory");   // this step's rows have landed
+            if (g == 0 && lane == 0)    // paces the helpers (which may sit on another XCD: agent-scope store)
                 __hip_atomic_store(a.progress + cl * 32, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            LDS_BARRIER();
+            if (LDS_FLAG_GET(s_abort)) break;
+        }
+    } else if (w == STORER_WAVE) {
+        for (int step = 0; step < T; ++step) {
+            LDS_BARRIER();        // the previous step's results are visible
+            const int aborted = LDS_FLAG_GET(s_abort);
+            if (step > 0) io_store_results(step - 1);
+            if (aborted) break;
+        }
+    } else {
+        // one step of a compute wave; `first` is a literal at both call sites, so the step-0 special cases fold away
+        auto compute_step = [&](const int step, const bool first) -> int {
+            const int t = step_t(step);
             STAMP(0);
-            if (w < IO_WAVE && step > 0) {
+            if (!first) {
                 const unsigned pbase = (unsigned)((step - 1) & 1) * SLOT;
                 // fresh word of epoch e: (bit0, bit16) = (e, 1-e); the two halves of a word are written by
                 // different lanes (2-byte stores), so BOTH bits are checked
@@ -505,12 +535,18 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
                         vl[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 16);
                     }
                 };
+#ifdef PGASR_LSTM_DIAG
+                if (a.diag & 8) { vh[0] = vh[1] = vl[0] = vl[1] = (u32x4){0u, 0u, 0u, 0u}; } else
+#endif
                 issue_loads();            // the operand loads ARE the poll
                 SpinGuard sg;
                 while (true) {
                     const unsigned bad = (bad4(vh[0], want) | bad4(vl[0], want)) | (bad4(vh[1], want) | bad4(vl[1], want));
                     if (!__any(bad != 0)) break;
-                    if (s_abort || !sg.keep_waiting()) { s_abort = 1; *a.err = 1; break; }
+#ifdef PGASR_LSTM_DIAG
+                    if (a.diag & 12) break;
+#endif
+                    if (LDS_FLAG_GET(s_abort) || !sg.keep_waiting()) { LDS_FLAG_SET(s_abort, 1); *a.err = 1; break; }
                     issue_loads();
                 }
                 STAMP(1);
@@ -520,79 +556,92 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
                     Hhi[i] = __builtin_bit_cast(bf16x8, vh[i]);
                     Hlo[i] = __builtin_bit_cast(bf16x8, vl[i]);
                 }
-                f32x4 acc[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[m][i], Hhi[i], acc[m], 0, 0, 0);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[m][i], Hlo[i], acc[m], 0, 0, 0);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wlo[m][i], Hhi[i], acc[m], 0, 0, 0);
-                }
+                // Two tile pairs, each pair's 12 MFMAs interleaved, and the first pair's partial tiles written to LDS while the
+                // second pair is multiplied: ds_write_b128 moves only ~80 B/clk per CU, i.e. the 16 KiB of partials are ~200
+                // cycles of LDS store time -- half of it sits under the MFMAs instead of behind them.
                 // tile m, lane (q,n): gates of local unit 4m+q for utterance n
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    *reinterpret_cast<float4*>(&part[step & 1][(w * 16 + n) * PROW + (4 * m + q) * 4]) =
-                        make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+                for (int half = 0; half < 2; ++half) {
+                    f32x4 acc[2];
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; ++m2) acc[m2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                        for (int m2 = 0; m2 < 2; ++m2) acc[m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[2 * half + m2][i], Hhi[i], acc[m2], 0, 0, 0);
+#pragma unroll
+                        for (int m2 = 0; m2 < 2; ++m2) acc[m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[2 * half + m2][i], Hlo[i], acc[m2], 0, 0, 0);
+#pragma unroll
+                        for (int m2 = 0; m2 < 2; ++m2) acc[m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wlo[2 * half + m2][i], Hhi[i], acc[m2], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; ++m2)
+                        *reinterpret_cast<float4*>(&part[step & 1][(w * 16 + n) * PROW + (4 * (2 * half + m2) + q) * 4]) =
+                            make_float4(acc[m2][0], acc[m2][1], acc[m2][2], acc[m2][3]);
+                    __builtin_amdgcn_sched_barrier(0);      // keep the first pair's stores in front of the second pair's MFMAs
+                }
                 STAMP(2);
             }
-            LDS_BARRIER();        // partial tiles + this step's xproj visible; previous step's results visible to the I/O wave
+            LDS_BARRIER();        // partial tiles + this step's xproj visible; previous step's results visible to the storer wave
             STAMP(3);
-            if (s_abort) goto done;
-            if (w == STORER_WAVE) {
-                if (step > 0) io_store_results(step - 1);
-            } else if (w < IO_WAVE) {
-                float4 pre = xin[step % FWD_RING][tid];
-                if (step > 0) {
-                    const float* pp = &part[step & 1][pn * PROW + pu * 4];
-                    const float4 p0 = *reinterpret_cast<const float4*>(pp);
-                    const float4 p1 = *reinterpret_cast<const float4*>(pp + 16 * PROW);
-                    const float4 p2 = *reinterpret_cast<const float4*>(pp + 32 * PROW);
-                    const float4 p3 = *reinterpret_cast<const float4*>(pp + 48 * PROW);
-                    pre.x += (p0.x + p1.x) + (p2.x + p3.x);
-                    pre.y += (p0.y + p1.y) + (p2.y + p3.y);
-                    pre.z += (p0.z + p1.z) + (p2.z + p3.z);
-                    pre.w += (p0.w + p1.w) + (p2.w + p3.w);
-                }
-                const float gi = sigmoidf_fast(pre.x);
-                const float gf = sigmoidf_fast(pre.y);
-                const float gg = tanhf_fast(pre.z);
-                const float go = sigmoidf_fast(pre.w);
-                const bool active = t < len;
-                const float cn = gf * c + gi * gg;
-                const float hn = go * tanhf_fast(cn);
-                if (active) { c = cn; h = hn; }
-                if (step + 1 < T) {
-                    // publish h_t: each cell thread writes its own bf16 hi and lo (2-byte stores);
-                    // layout [kc = unit/8][n][hl][unit%8] of this member's 1-KiB block
-                    const unsigned e = (unsigned)(step >> 1) & 1u;
-                    const unsigned tb = (pu & 1) ? (1u - e) : e;
-                    unsigned short hi, lo;
-                    split_tagged(h, tb, hi, lo);
-                    const unsigned off = (unsigned)(step & 1) * SLOT + (unsigned)g * 1024u +
-                                         (unsigned)((((pu >> 3) * 16 + pn) * 2) * 16 + (pu & 7) * 2);
-                    if (same_xcd) {
-                        __builtin_amdgcn_raw_buffer_store_b16(hi, rsrc, off, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b16(lo, rsrc, off + 16, 0, 0);
-                    } else {
-                        __builtin_amdgcn_raw_buffer_store_b16(hi, rsrc, off, 0, 16);
-                        __builtin_amdgcn_raw_buffer_store_b16(lo, rsrc, off + 16, 0, 16);
-                    }
-                }
-                // results for the backward pass / next layer: staged in LDS, written out by the I/O wave
-                rg[step & 1][tid] = active ? make_float4(gi, gf, gg, go) : make_float4(0, 0, 0, 0);
-                rc[step & 1][tid] = c;
-                rh[step & 1][tid] = active ? hn : 0.f;
+            const int aborted = LDS_FLAG_GET(s_abort);
+            float4 pre = xin[step % FWD_RING][tid];
+            if (!first) {
+                const float* pp = &part[step & 1][pn * PROW + pu * 4];
+                const float4 p0 = *reinterpret_cast<const float4*>(pp);
+                const float4 p1 = *reinterpret_cast<const float4*>(pp + 16 * PROW);
+                const float4 p2 = *reinterpret_cast<const float4*>(pp + 32 * PROW);
+                const float4 p3 = *reinterpret_cast<const float4*>(pp + 48 * PROW);
+                pre.x += (p0.x + p1.x) + (p2.x + p3.x);
+                pre.y += (p0.y + p1.y) + (p2.y + p3.y);
+                pre.z += (p0.z + p1.z) + (p2.z + p3.z);
+                pre.w += (p0.w + p1.w) + (p2.w + p3.w);
             }
+            STAMP(4);
+            const float gi = sigmoidf_fast(pre.x);
+            const float gf = sigmoidf_fast(pre.y);
+            const float gg = tanhf_fast(pre.z);
+            const float go = sigmoidf_fast(pre.w);
+            const bool active = t < len;
+            const float cn = gf * c + gi * gg;
+            const float hn = go * tanhf_fast(cn);
+            if (active) { c = cn; h = hn; }
+#ifdef PGASR_LSTM_DIAG
+            if (!(a.diag & 16))
+#endif
+            {
+                // publish h_t (also after the last step: nobody reads that slot, and lstm_prepare_kernel resets it): each cell
+                // thread writes its own bf16 hi and lo (2-byte stores); layout [kc = unit/8][n][hl][unit%8] of this member's 1-KiB block
+                const unsigned e = (unsigned)(step >> 1) & 1u;
+                const unsigned tb = (pu & 1) ? (1u - e) : e;
+                unsigned short hi, lo;
+                split_tagged(h, tb, hi, lo);
+                const unsigned off = (unsigned)(step & 1) * SLOT + (unsigned)g * 1024u +
+                                     (unsigned)((((pu >> 3) * 16 + pn) * 2) * 16 + (pu & 7) * 2);
+                if (same_xcd) {
+                    __builtin_amdgcn_raw_buffer_store_b16(hi, rsrc, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16(lo, rsrc, off + 16, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b16(hi, rsrc, off, 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b16(lo, rsrc, off + 16, 0, 16);
+                }
+            }
+            STAMP(5);
+            // results for the backward pass / next layer: staged in LDS, written out by the storer wave
+            rg[step & 1][tid] = active ? make_float4(gi, gf, gg, go) : make_float4(0, 0, 0, 0);
+            rc[step & 1][tid] = c;
+            rh[step & 1][tid] = active ? hn : 0.f;
             STAMP(6);
+            return aborted;
+        };
+        if (T > 0 && !compute_step(0, true)) {
+            for (int step = 1; step < T; ++step)
+                if (compute_step(step, false)) break;
         }
     }
-done:
+    STAMP_FLUSH();
     __syncthreads();
-    if (w == STORER_WAVE && !s_abort && T > 0) io_store_results(T - 1);
+    if (w == STORER_WAVE && !LDS_FLAG_GET(s_abort) && T > 0) io_store_results(T - 1);
     release_xcd(a, g, tid);
 }
 
@@ -623,9 +672,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) float sct[BWD_RING][256];              // c_t ring (c_prev of step s = c_t of step s+1)
     __shared__ __attribute__((aligned(16))) float sdy[BWD_RING][256];              // dout ring
     __shared__ __attribute__((aligned(16))) float4 rdg[2][256];                    // results: d(pre-activation gates)
-    __shared__ volatile int s_abort;
-    __shared__ volatile int s_same;
-    if (tid == 0) { s_abort = 0; s_same = 0; }
+    __shared__ int s_abort;
+    __shared__ int s_same;
+    if (tid == 0) { LDS_FLAG_SET(s_abort, 0); LDS_FLAG_SET(s_same, 0); }
     __syncthreads();
 
     // A operand tiles: output units 16*(4w+mt)..+15 (rows), k = own gate rows r' = 64g + 32i + ..
@@ -644,7 +693,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     constexpr unsigned SLOT = 16 * 16 * 256 * 4;      // [src 16][dst 16][n 16][unit 16] fp32 = 256 KiB
     unsigned char* xb = a.xbuf + (size_t)cl * (2 * SLOT);
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)(2 * SLOT), 0x00020000);
-    const bool same_xcd = cluster_same_xcd(a, cl, g, tid, &s_same, &s_abort);
+    const bool same_xcd = cluster_same_xcd(a, cl, g, tid, s_same, s_abort);
 
     const int bidx = bg * 16 + pn;
     const int len = (bidx < B) ? a.lengths[bidx] : 0;
@@ -662,7 +711,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
         while (true) {
             POLL_FENCE();
             if (__hip_atomic_load(ready + (s % RING_STEPS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(s + 1)) break;
-            if (s_abort || !sgr.keep_waiting()) { s_abort = 1; *a.err = 1; break; }
+            if (LDS_FLAG_GET(s_abort) || !sgr.keep_waiting()) { LDS_FLAG_SET(s_abort, 1); *a.err = 1; break; }
             __builtin_amdgcn_s_sleep(1);
         }
     };
@@ -710,86 +759,106 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     }
     LDS_BARRIER();
 
-    {
+    // Role-specialised loops, one LDS barrier per step each (see lstm_fwd_kernel).
+    if (w == LOADER_WAVE) {
         for (int step = 0; step < T; ++step) {
-            const int t = step_t(step);
-            if (g == 0 && tid == 0)     // paces the helpers
+            if (g == 0 && lane == 0)     // paces the helpers
                 __hip_atomic_store(a.progress + cl * 32, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // cells of step+1 read rows(step+1) and c_t(step+2) before the NEXT barrier: keep only the two
+            // youngest steps (12 instructions) in flight
+            loader_issue(step + BWD_LEAD);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            LDS_BARRIER();
+            if (LDS_FLAG_GET(s_abort)) break;
+        }
+    } else if (w == STORER_WAVE) {
+        for (int step = 0; step < T; ++step) {
+            LDS_BARRIER();
+            const int aborted = LDS_FLAG_GET(s_abort);
+            io_store_results(step);
+            if (aborted) break;
+        }
+    } else {
+        auto compute_step = [&](const int step, const bool first) -> int {
+            const int t = step_t(step);
             float4 d = make_float4(0, 0, 0, 0);
             unsigned short* dbuf = &dgl[(step & 1) * (16 * 2 * 64)];
-            if (w == LOADER_WAVE) {
-                // cells of step+1 read rows(step+1) and c_t(step+2) before the NEXT barrier: keep only the two
-                // youngest steps (12 instructions) in flight
-                loader_issue(step + BWD_LEAD);
-                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            } else if (w < IO_WAVE) {
-                // everything that does not need the incoming dh is done BEFORE the poll (the rows of this step have
-                // been in the LDS ring since the previous barrier): after the hand-off only five multiply-adds remain
-                const bool active = t < len;
-                const float4 gt = sg_[step % BWD_RING][tid];
-                const float ct = sct[step % BWD_RING][tid], dy = sdy[step % BWD_RING][tid];
-                const float cp = (step + 1 < T) ? sct[(step + 1) % BWD_RING][tid] : 0.f;
-                const float gi = gt.x, gf = gt.y, gg = gt.z, go = gt.w;
-                const float tc = tanhf_fast(ct);
-                const float k_c = go * (1.f - tc * tc);          // d(dh) -> d(c)
-                const float k_i = gg * gi * (1.f - gi), k_f = cp * gf * (1.f - gf), k_g = gi * (1.f - gg * gg), k_o = tc * go * (1.f - go);
-                float dh_rec = carry;
-                if (step > 0) {
-                    // slot layout [src 16][dst 16][n 16][16 units]: what one member reads from one source is ONE contiguous KiB
-                    // (a wave's load = 256 contiguous bytes), and what a wave publishes for one destination as well
-                    const unsigned pbase = (unsigned)((step - 1) & 1) * SLOT + (unsigned)((g * 256 + pn * 16 + pu) * 4);
-                    const unsigned stale_bit = (((step - 1) >> 1) & 1) ? 0x2u : 0x1u;
-                    float v[16];
-                    SpinGuard sg;
-                    // The partial sums cannot be there earlier than one hand-off after this member's own publish, and a
-                    // poll is 16 KiB per workgroup through the L2 that the other members' 16-KiB publishes are still
-                    // entering: hold the first poll back (x64 cycles).  Measured stand-alone 0: 1.61, 6: 1.59, 8: 1.55,
-                    // 10: 1.52-1.57, 14: 1.61 us per step; train step 11.82 -> 11.64 ms with 10.  Re-measured after the dh-independent
-                    // cell work moved in front of the poll: 6: 1.42, 8: 1.41, 10: 1.45, 12: 1.50, 14: 1.55; and again with the
-                    // [src][dst][n][unit] slot layout (publishes land sooner): 0-4: 1.26-1.30, 6: 1.32, 8: 1.37, 10: 1.43 -> 2.  (The forward sweep
-                    // publishes 1 KiB per member and only loses from a delay: 1.15 -> 1.19 / 1.30 / 1.37 for 4 / 8 / 12.)
-                    __builtin_amdgcn_s_sleep(PGASR_BWD_POLL_DELAY);
-                    while (true) {
-                        POLL_FENCE();
-                        unsigned orr = 0;
+            // everything that does not need the incoming dh is done BEFORE the poll (the rows of this step have
+            // been in the LDS ring since the previous barrier): after the hand-off only five multiply-adds remain
+            const bool active = t < len;
+            const float4 gt = sg_[step % BWD_RING][tid];
+            const float ct = sct[step % BWD_RING][tid], dy = sdy[step % BWD_RING][tid];
+            const float cp = (step + 1 < T) ? sct[(step + 1) % BWD_RING][tid] : 0.f;
+            const float gi = gt.x, gf = gt.y, gg = gt.z, go = gt.w;
+            const float tc = tanhf_fast(ct);
+            const float k_c = go * (1.f - tc * tc);          // d(dh) -> d(c)
+            const float k_i = gg * gi * (1.f - gi), k_f = cp * gf * (1.f - gf), k_g = gi * (1.f - gg * gg), k_o = tc * go * (1.f - go);
+            float dh_rec = carry;
+            if (!first) {
+                // slot layout [src 16][dst 16][n 16][16 units]: what one member reads from one source is ONE contiguous KiB
+                // (a wave's load = 256 contiguous bytes), and what a wave publishes for one destination as well
+                const unsigned pbase = (unsigned)((step - 1) & 1) * SLOT + (unsigned)((g * 256 + pn * 16 + pu) * 4);
+                const unsigned stale_bit = (((step - 1) >> 1) & 1) ? 0x2u : 0x1u;
+                float v[16];
+                SpinGuard sg;
+                // The partial sums cannot be there earlier than one hand-off after this member's own publish, and a
+                // poll is 16 KiB per workgroup through the L2 that the other members' 16-KiB publishes are still
+                // entering: hold the first poll back (x64 cycles).  Measured stand-alone 0: 1.61, 6: 1.59, 8: 1.55,
+                // 10: 1.52-1.57, 14: 1.61 us per step; train step 11.82 -> 11.64 ms with 10.  Re-measured after the dh-independent
+                // cell work moved in front of the poll: 6: 1.42, 8: 1.41, 10: 1.45, 12: 1.50, 14: 1.55; and again with the
+                // [src][dst][n][unit] slot layout (publishes land sooner): 0-4: 1.26-1.30, 6: 1.32, 8: 1.37, 10: 1.43 -> 2.  (The forward sweep
+                // publishes 1 KiB per member and only loses from a delay: 1.15 -> 1.19 / 1.30 / 1.37 for 4 / 8 / 12.)
+                __builtin_amdgcn_s_sleep(PGASR_BWD_POLL_DELAY);
+                while (true) {
+                    POLL_FENCE();
+                    unsigned orr = 0;
+#ifdef PGASR_LSTM_DIAG
+                    if (a.diag & 8) {
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) v[s] = 0.f;
+                    } else
+#endif
+                    {
 #pragma unroll
                         for (int s = 0; s < 16; ++s) {
                             const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(rsrc, pbase + (unsigned)s * (16 * 256 * 4), 0, 16);
                             orr |= u;
                             v[s] = __uint_as_float(u);
                         }
-                        if (!__any((orr & stale_bit) != 0)) break;
-                        if (s_abort || !sg.keep_waiting()) { s_abort = 1; *a.err = 1; break; }
                     }
-                    float sum = 0.f;
+                    if (!__any((orr & stale_bit) != 0)) break;
+#ifdef PGASR_LSTM_DIAG
+                    if (a.diag & 12) break;
+#endif
+                    if (LDS_FLAG_GET(s_abort) || !sg.keep_waiting()) { LDS_FLAG_SET(s_abort, 1); *a.err = 1; break; }
+                }
+                float sum = 0.f;
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) sum += v[s];     // fixed order: reproducible
-                    dh_rec += sum;
-                }
-                const float dh = dy + dh_rec;
-                const float dct = dh * k_c + dc;
-                d.x = dct * k_i;
-                d.y = dct * k_f;
-                d.z = dct * k_g;
-                d.w = dh * k_o;
-                if (active) { dc = dct * gf; carry = 0.f; }
-                else { d = make_float4(0, 0, 0, 0); carry = dh_rec; }
-                dbs.x += d.x; dbs.y += d.y; dbs.z += d.z; dbs.w += d.w;
-                {
-                    unsigned short hi[4], lo[4];
-                    split_plain(d.x, hi[0], lo[0]); split_plain(d.y, hi[1], lo[1]);
-                    split_plain(d.z, hi[2], lo[2]); split_plain(d.w, hi[3], lo[3]);
-                    unsigned short* dst = &dbuf[(pn * 2) * 64 + pu * 4];      // [n][hl][r' local = 4*pu + gate]
-                    *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
-                    *reinterpret_cast<uint2*>(dst + 64) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
-                }
-                rdg[step & 1][tid] = d;      // written to HBM by the I/O wave after the barrier
+                for (int s = 0; s < 16; ++s) sum += v[s];     // fixed order: reproducible
+                dh_rec += sum;
             }
+            const float dh = dy + dh_rec;
+            const float dct = dh * k_c + dc;
+            d.x = dct * k_i;
+            d.y = dct * k_f;
+            d.z = dct * k_g;
+            d.w = dh * k_o;
+            if (active) { dc = dct * gf; carry = 0.f; }
+            else { d = make_float4(0, 0, 0, 0); carry = dh_rec; }
+            dbs.x += d.x; dbs.y += d.y; dbs.z += d.z; dbs.w += d.w;
+            {
+                unsigned short hi[4], lo[4];
+                split_plain(d.x, hi[0], lo[0]); split_plain(d.y, hi[1], lo[1]);
+                split_plain(d.z, hi[2], lo[2]); split_plain(d.w, hi[3], lo[3]);
+                unsigned short* dst = &dbuf[(pn * 2) * 64 + pu * 4];      // [n][hl][r' local = 4*pu + gate]
+                *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
+                *reinterpret_cast<uint2*>(dst + 64) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+            }
+            rdg[step & 1][tid] = d;      // written to HBM by the storer wave after the barrier
             LDS_BARRIER();
-            if (s_abort) goto done;
-            if (w == STORER_WAVE) {
-                io_store_results(step);
-            } else if (w < IO_WAVE && step + 1 < T) {
+            const int aborted = LDS_FLAG_GET(s_abort);       // read behind the barrier, used at the end of the step
+            {
+                // (also after the last step: nobody reads that slot, and lstm_prepare_kernel resets it)
                 bf16x8 Dhi[2], Dlo[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -799,6 +868,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
                 const unsigned e = (unsigned)(step >> 1) & 1u;
                 const unsigned tag = e ? 0x1u : 0x2u;       // (bit0, bit1) = (e, 1-e)
                 const unsigned obase = (unsigned)(step & 1) * SLOT + (unsigned)g * (16 * 256 * 4);
+#ifdef PGASR_LSTM_DIAG
+                const bool no_publish = (a.diag & 16) != 0;
+#endif
                 // two tile pairs: the first pair is on its way to L2 while the second is still being multiplied (the
                 // 16 KiB this workgroup publishes per step is the start of everybody else's hand-off)
 #pragma unroll
@@ -825,11 +897,19 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
                         o.w = (__float_as_uint(acc[m2][3]) & ~3u) | tag;
                         // lane (q,n), tile 4w+mt: output units 16(4w+mt) + 4q .. +3 for utterance n
                         const unsigned off = obase + (unsigned)(((4 * w + mt) * 256 + n * 16 + 4 * q) * 4);
+#ifdef PGASR_LSTM_DIAG
+                        if (no_publish) continue;
+#endif
                         if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 0);
                         else          __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 16);
                     }
                 }
             }
+            return aborted;
+        };
+        if (T > 0 && !compute_step(0, true)) {
+            for (int step = 1; step < T; ++step)
+                if (compute_step(step, false)) break;
         }
     }
     if (a.dbias_part) {
@@ -847,7 +927,6 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
             *reinterpret_cast<float4*>(a.dbias_part + (((size_t)bg * 2 + dir) * HID + 16 * g + tid) * 4) = sum;
         }
     }
-done:
     release_xcd(a, g, tid);
 }
 

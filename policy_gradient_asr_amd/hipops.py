@@ -371,7 +371,8 @@ def _lstm_ws(T, B, backward, device):
     return _workspace(nbytes, device, "lstm_bwd" if backward else "lstm_fwd")
 
 
-LSTM_FLAGS = 0   # bit 0: force the write-through (cross-XCD) hand-off protocol
+import os as _os
+LSTM_FLAGS = int(_os.environ.get("PGASR_LSTM_FLAGS", "0"), 0)   # bit 0: force the write-through (cross-XCD) hand-off protocol; bits 8..: diagnostics
 
 
 def lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, fed=None, fed_need=0):

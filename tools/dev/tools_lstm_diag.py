@@ -28,5 +28,7 @@ def run(flags, bwd=False):
     e1.record(); torch.cuda.synchronize()
     hipops.LSTM_FLAGS = 0
     return e0.elapsed_time(e1) / 3
-for name, fl in (("normal", 0), ("no stores", 1 << 8), ("no loads", 2 << 8), ("no stores+no loads", 3 << 8), ("write-through", 1)):
+for name, fl in (("normal", 0), ("no stores", 1 << 8), ("no loads", 2 << 8), ("no stores+no loads", 3 << 8), ("write-through", 1),
+                 ("first poll taken (no dependency)", 4 << 8), ("no exchange loads", 8 << 8), ("no exchange loads, no publish", 24 << 8),
+                 ("compute chain only (no I/O at all)", 27 << 8)):
     print(f"fwd {name:20s}: {run(fl):.3f} ms   bwd: {run(fl, True):.3f} ms", flush=True)

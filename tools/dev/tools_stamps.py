@@ -18,6 +18,7 @@ wih, bias, pf, pb = hipops.lstm_pack(params, 512)
 gates = torch.randn(T, B, 2048, generator=g).to(dev)
 out = torch.empty(T, B, 512, device=dev); cbuf = torch.empty(T, B, 512, device=dev)
 lengths = torch.full((B,), T, dtype=torch.int32, device=dev)
+hipops.LSTM_FLAGS = int(os.environ.get("PGASR_LSTM_FLAGS", "0"), 0)
 for it in range(3):
     ws = hipops.lstm_layer_fwd(gates.clone(), out, cbuf, pf, lengths, T, B)
 torch.cuda.synchronize()
@@ -25,13 +26,15 @@ nb = lib.pgasr_lstm_workspace_bytes(T, B, 0)
 hello = ws[256:256 + 4 * 16 * 4].view(torch.int32).view(4, 16).cpu()
 print("XCC id per cluster member (rows = clusters):")
 print((hello & 0xF).tolist())
-st = ws[nb - 4096 * 64: nb].view(torch.int64).view(4096, 8)[:T].cpu().double()
-d = st[5:T - 5]
-segs = [(0, 1, "poll: h_{t-1} words valid"), (1, 2, "MFMA + partial write"), (2, 3, "LDS barrier"), (3, 6, "sum + cell + publish")]
-tot = (d[1:, 0] - d[:-1, 0]).mean()
-print(f"cycles per step (100 MHz wall clock x?): {tot:.0f}")
-for i, j, nme in segs:
-    x = d[:, j] - d[:, i]
-    print(f"  {nme:28s} {x.mean():8.0f}  (min {x.min():.0f}, p50 {x.median():.0f}, max {x.max():.0f})")
-x = d[1:, 0] - d[:-1, 6]
-print(f"  {'loop back (loader/progress)':28s} {x.mean():8.0f}  (min {x.min():.0f}, p50 {x.median():.0f}, max {x.max():.0f})")
+hw = (hello >> 16) & 0xFFFF
+print("CU id (HW_ID[11:8]) / SH / SE per member:")
+for r in range(4):
+    print([f"se{(int(v) >> 13) & 7}.sh{(int(v) >> 12) & 1}.cu{(int(v) >> 8) & 15}" for v in hw[r].tolist()])
+    ids = [int(v) >> 8 for v in hw[r].tolist()]
+    print("   distinct CUs:", len(set(ids)), "of", len(ids))
+st = ws[nb - 4096 * 64: nb].view(torch.int64)[:8].cpu().double() / T
+names = {0: "loop top (loader section, progress word)", 1: "poll: h_{t-1} words valid", 2: "MFMA + partial write", 3: "LDS barrier",
+         4: "LDS reads + 4-way sum", 5: "cell math + publish", 6: "result staging (LDS writes)"}
+print(f"cycles per step: {float(st.sum()):.0f}  (flags {hipops.LSTM_FLAGS:#x})")
+for k, nme in names.items():
+    print(f"  {nme:42s} {float(st[k]):8.0f}")
