@@ -429,6 +429,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
+    host_enqueue_s = time.perf_counter() - t0       # how long the host needed to ENQUEUE the steps (it runs ahead of the GPU)
     barrier()
     dt_local = time.perf_counter() - t0
     if rank == 0:
@@ -511,6 +512,7 @@ def main():
                               "frac_vs_bf16x3_peak_833": step_tf / peak, "frac_vs_fp32_mfma_peak_157.3": step_tf / FP32_MFMA_PEAK_TF,
                               "note": "whole-step dense contraction flops (SURVEY §8d: 28.65 GFLOP per 1000-frame utterance) per GPU / ms_per_step"},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
             "loss": float(loss.item()),
         }
         if ar is not None:

@@ -266,8 +266,12 @@ int pgasr_stream_gate(const unsigned* words, int count, int timeout_us, void* st
  * (they do not under kernel-serialising profilers / launch-blocking modes / a single hardware queue).  The fed sweeps
  * below REQUIRE that concurrency; callers probe once per stream pair and otherwise use the sequential order. */
 int pgasr_stream_probe(unsigned* words, int timeout_us, void* stream);
+/* out_drop (optional, with drop_p in (0,1)): the sweep also writes dropout(out) there -- nn.LSTM's inter-layer dropout
+ * (model.py:42), i.e. the NEXT layer's input, with exactly pgasr_dropout(out, drop_p, drop_seed, drop_offset)'s mask;
+ * out itself stays un-dropped (the backward pass needs h_t).  NULL / 0: no second output. */
 int pgasr_lstm_layer_fwd(float* gates, float* out, float* cbuf, const void* whh_pack_fwd,
                          const int32_t* lengths, int T, int B, int flags,
+                         float* out_drop, float drop_p, uint64_t drop_seed, uint32_t drop_offset,
                          void* workspace, size_t workspace_bytes, void* stream);
 /* pgasr_lstm_layer_fwd whose gates rows are produced WHILE it runs by pgasr_gemm_x3w_feed_f32 (launched after this
  * call on another stream): fed = that call's tiles_done, fed_need = 8H/256 column tiles per direction.  The helper
@@ -276,6 +280,7 @@ int pgasr_lstm_layer_fwd(float* gates, float* out, float* cbuf, const void* whh_
  * pgasr_lstm_fed_ok(T, B, flags) != 0 says beforehand whether this call is possible. */
 int pgasr_lstm_layer_fwd_fed(float* gates, float* out, float* cbuf, const void* whh_pack_fwd,
                              const int32_t* lengths, int T, int B, int flags, const unsigned* fed, int fed_need,
+                             float* out_drop, float drop_p, uint64_t drop_seed, uint32_t drop_offset,
                              void* workspace, size_t workspace_bytes, void* stream);
 int pgasr_lstm_fed_ok(int T, int B, int flags);
 /* Backward counterpart: dout (= the input gradient of the layer above) is produced while the sweep runs by

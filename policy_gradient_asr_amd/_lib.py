@@ -76,9 +76,9 @@ SIGNATURES = {
     "pgasr_stream_gate": (C.c_int, [c_ptr, C.c_int, C.c_int, c_ptr]),
     "pgasr_stream_probe": (C.c_int, [c_ptr, C.c_int, c_ptr]),
     "pgasr_lstm_layer_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int,
-                                       c_ptr, C.c_size_t, c_ptr]),
+                                       c_f32p, C.c_float, C.c_uint64, C.c_uint32, c_ptr, C.c_size_t, c_ptr]),
     "pgasr_lstm_layer_fwd_fed": (C.c_int, [c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int, c_ptr, C.c_int,
-                                           c_ptr, C.c_size_t, c_ptr]),
+                                           c_f32p, C.c_float, C.c_uint64, C.c_uint32, c_ptr, C.c_size_t, c_ptr]),
     "pgasr_lstm_fed_ok": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pgasr_lstm_layer_bwd_fed": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int,
                                            c_f32p, c_ptr, C.c_int, C.c_float, C.c_uint64, C.c_uint32, c_ptr, C.c_size_t, c_ptr]),

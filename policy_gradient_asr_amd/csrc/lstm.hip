@@ -73,6 +73,7 @@ struct LstmArgs {
     float* gates;            // [T][B][2][H][4]: in = permuted xproj (+biases); out = activations i,f,g,o;
                              // after the backward sweep: d(pre-activations)
     float* out;              // [T][B][2H]   h_t (zeros past each length)
+    float* out_drop;         // (forward, optional) [T][B][2H] = dropout(out): the next layer's input (model.py:42), written by the storer wave
     float* cbuf;             // [T][B][2][H] c_t
     const float* dout;       // [T][B][2H]   (backward) gradient w.r.t. out
     float* dbias_part;       // (backward, optional) [ceil(B/16)][2][H][4]: per 16-utterance group sums over t of dgates
@@ -490,7 +491,21 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
         const int cell0 = 4 * lane, b = bg * 16 + (cell0 >> 4), u0 = 16 * g + (cell0 & 15);
         if (b < B) {
             *reinterpret_cast<float4*>(a.cbuf + (((size_t)t * B + b) * 2 + dir) * HID + u0) = *reinterpret_cast<const float4*>(&rc[par][cell0]);
-            *reinterpret_cast<float4*>(a.out + ((size_t)t * B + b) * (2 * HID) + dir * HID + u0) = *reinterpret_cast<const float4*>(&rh[par][cell0]);
+            const float4 hv = *reinterpret_cast<const float4*>(&rh[par][cell0]);
+            const size_t oi = ((size_t)t * B + b) * (2 * HID) + dir * HID + u0;
+            *reinterpret_cast<float4*>(a.out + oi) = hv;
+            if (a.out_drop) {
+                // nn.LSTM's inter-layer dropout (model.py:42) on the way out: the mask pgasr_dropout would give this tensor
+                // (one Philox call per 4 consecutive elements), so the separate 2 x 65 MB pass and its launch disappear
+                uint32_t r[4];
+                philox4x32_10((uint32_t)(oi >> 2), (uint32_t)((oi >> 2) >> 32), a.drop_off, 0u, a.drop_k0, a.drop_k1, r);
+                float4 dv;
+                dv.x = r[0] >= a.drop_thresh ? hv.x * a.drop_scale : 0.f;
+                dv.y = r[1] >= a.drop_thresh ? hv.y * a.drop_scale : 0.f;
+                dv.z = r[2] >= a.drop_thresh ? hv.z * a.drop_scale : 0.f;
+                dv.w = r[3] >= a.drop_thresh ? hv.w * a.drop_scale : 0.f;
+                *reinterpret_cast<float4*>(a.out_drop + oi) = dv;
+            }
         }
     };
     // Three role-specialised loops with ONE LDS barrier per step each (the counts must match).  One shared loop with
@@ -1104,7 +1119,7 @@ extern "C" size_t pgasr_lstm_workspace_bytes(int T, int B, int backward) {
 static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, const float* dout, float* dbias_part, const void* wpack,
                        const int* lengths, int T, int B, int flags, void* workspace, size_t workspace_bytes, hipStream_t st,
                        const unsigned* fed = nullptr, int fed_need = 0, float drop_p = 0.f, uint64_t drop_seed = 0,
-                       uint32_t drop_offset = 0) {
+                       uint32_t drop_offset = 0, float* out_drop = nullptr) {
     if (!gates || !out || !cbuf || !wpack || !lengths || T <= 0 || B <= 0) return PGASR_ERR_INVALID_ARG;
     if (backward && !dout) return PGASR_ERR_INVALID_ARG;
     const WsLayout l = lstm_ws_layout(B, backward);
@@ -1119,7 +1134,7 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
                        (u32x4*)(ws + l.xbuf), (unsigned)(l.xbytes / 16));
     PGASR_CHECK_LAUNCH();
     LstmArgs a;
-    a.gates = gates; a.out = out; a.cbuf = cbuf; a.dout = dout; a.dbias_part = dbias_part; a.wpack = (const u32x4*)wpack;
+    a.gates = gates; a.out = out; a.out_drop = out_drop; a.cbuf = cbuf; a.dout = dout; a.dbias_part = dbias_part; a.wpack = (const u32x4*)wpack;
     a.xbuf = (unsigned char*)(ws + l.xbuf); a.hello = (unsigned*)(ws + l.hello); a.err = (int*)(ws + l.err);
     a.busy = (unsigned*)(ws + l.err + 64);   // 8 words inside the zeroed 256-byte head block
     a.progress = (unsigned*)(ws + l.progress);
@@ -1142,8 +1157,10 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
         if ((size_t)T * B * 2 * HID * 4 * 4 >= ((size_t)1 << 31)) return PGASR_ERR_UNSUPPORTED;     // buffer-addressed loads
     }
     a.drop_on = 0; a.drop_thresh = 0; a.drop_scale = 1.f; a.drop_k0 = a.drop_k1 = a.drop_off = 0;
+    if (out_drop && (backward || drop_p == 0.f || (((size_t)out_drop) & 15))) return PGASR_ERR_INVALID_ARG;
     if (drop_p != 0.f) {
-        if (!fed || !backward || !(drop_p > 0.f) || !(drop_p < 1.f)) return PGASR_ERR_INVALID_ARG;
+        // backward: the mask is applied to the fed dout rows by the helpers; forward: to out on its way to out_drop
+        if ((backward && !fed) || (!backward && !out_drop) || !(drop_p > 0.f) || !(drop_p < 1.f)) return PGASR_ERR_INVALID_ARG;
         a.drop_on = 1;
         a.drop_thresh = (uint32_t)fmin(4294967295.0, (double)drop_p * 4294967296.0);      // as pgasr_dropout
         a.drop_scale = 1.f / (1.f - drop_p);
@@ -1158,9 +1175,10 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
 
 extern "C" int pgasr_lstm_layer_fwd(float* gates, float* out, float* cbuf, const void* whh_pack_fwd,
                                     const int32_t* lengths, int T, int B, int flags,
+                                    float* out_drop, float drop_p, uint64_t drop_seed, uint32_t drop_offset,
                                     void* workspace, size_t workspace_bytes, void* stream) {
     return lstm_launch(false, gates, out, cbuf, nullptr, nullptr, whh_pack_fwd, lengths, T, B, flags, workspace, workspace_bytes,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream, nullptr, 0, drop_p, drop_seed, drop_offset, out_drop);
 }
 
 // Forward sweep whose input projection is produced WHILE it runs (pgasr_gemm_x3w_feed_f32 on another stream, launched
@@ -1170,10 +1188,11 @@ extern "C" int pgasr_lstm_layer_fwd(float* gates, float* out, float* cbuf, const
 // pgasr_lstm_layer_fwd instead.  pgasr_lstm_fed_ok answers the same question without launching.
 extern "C" int pgasr_lstm_layer_fwd_fed(float* gates, float* out, float* cbuf, const void* whh_pack_fwd,
                                         const int32_t* lengths, int T, int B, int flags, const unsigned* fed, int fed_need,
+                                        float* out_drop, float drop_p, uint64_t drop_seed, uint32_t drop_offset,
                                         void* workspace, size_t workspace_bytes, void* stream) {
     if (!fed) return PGASR_ERR_INVALID_ARG;
     return lstm_launch(false, gates, out, cbuf, nullptr, nullptr, whh_pack_fwd, lengths, T, B, flags, workspace, workspace_bytes,
-                       (hipStream_t)stream, fed, fed_need);
+                       (hipStream_t)stream, fed, fed_need, drop_p, drop_seed, drop_offset, out_drop);
 }
 
 // Backward sweep whose dout rows are produced WHILE it runs: dout = the input gradient of the layer above, written by

@@ -238,7 +238,10 @@ class BLSTMLayerFn(torch.autograd.Function):
     per-utterance lengths (packed-sequence semantics of model.py:52-55)."""
 
     @staticmethod
-    def forward(ctx, x, lengths, dact_y, sweep_follows, prepacked, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+    def forward(ctx, x, lengths, dact_y, sweep_follows, prepacked, out_dropout, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        """out_dropout = (p, seed, offset) or None: the layer RETURNS dropout(out) -- nn.LSTM's inter-layer dropout
+        (model.py:42), written by the sweep's storer waves next to out -- instead of out; backward applies the same mask to
+        the incoming gradient (or hands it to the helpers of its fed sweep)."""
         T, B, I = x.shape
         x = x.contiguous()
         if prepacked is None:
@@ -253,6 +256,9 @@ class BLSTMLayerFn(torch.autograd.Function):
         gates = torch.empty(T, B, G, dtype=torch.float32, device=x.device)
         out = torch.empty(T, B, 2 * HID, dtype=torch.float32, device=x.device)
         cbuf = torch.empty(T, B, 2 * HID, dtype=torch.float32, device=x.device)
+        ctx.out_dropout = tuple(out_dropout) if out_dropout is not None else None
+        out_drop = torch.empty_like(out) if out_dropout is not None else None
+        dkw = {"out_drop": out_drop, "drop": ctx.out_dropout}
         x3w = prepacked.planes is not None and hipops.gemm_x3w_ok(T * B, G, I)   # LDS-DMA kernel, pre-split weight planes
         if x3w and FEED_AHEAD and hipops.lstm_fed_ok(T, B) and hipops.streams_concurrent(grad_overlap.second_side_stream()):
             # the projection leaves the critical path: the sweep is launched FIRST and its helper workgroups wait for
@@ -266,7 +272,7 @@ class BLSTMLayerFn(torch.autograd.Function):
                 done = torch.zeros(need_words, dtype=torch.int32, device=x.device)
             zeroed = torch.cuda.Event()
             zeroed.record()
-            hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, fed=done, fed_need=G // 256)
+            hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, fed=done, fed_need=G // 256, **dkw)
             side.wait_event(zeroed)
             busy = hipops.lstm_busy_ptr(T, B, False, x.device)
             with torch.cuda.stream(side):
@@ -280,12 +286,12 @@ class BLSTMLayerFn(torch.autograd.Function):
                 hipops.gemm_x3w(x, prepacked.planes, gates, T * B, G, I, bias=bias_perm)
             else:
                 hipops.gemm(x, wih_perm, gates, M=T * B, N=G, K=I, transB=True, bias=bias_perm)
-            hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B)
+            hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, **dkw)
         ctx.save_for_backward(x, lengths, gates, out, cbuf, wih_perm, pack_b, dact_y if dact_y is not None else x.new_empty(0))
         ctx.has_dact = dact_y is not None
         ctx.sweep_follows = bool(sweep_follows)   # backward: another layer's sweep runs right after this one
         ctx.param_refs = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
-        return out
+        return out if out_drop is None else out_drop
 
     @staticmethod
     def backward(ctx, dout):
@@ -295,6 +301,12 @@ class BLSTMLayerFn(torch.autograd.Function):
         dev = x.device
         dout = dout.contiguous()
         rec = grad_overlap._deferred.pop(dout.data_ptr(), None) if grad_overlap.enabled else None
+        if ctx.out_dropout is not None:
+            # forward returned dropout(out): the gradient w.r.t. out is the same mask applied to dout
+            if rec is not None and rec["drop"] is None and dout.shape == rec["dx"].shape:
+                rec["drop"] = ctx.out_dropout      # dout does not exist yet: the fed sweep's helpers mask the rows they stage
+            else:
+                dout = hipops.dropout(dout, *ctx.out_dropout)
         if grad_overlap.enabled:
             before = torch.cuda.Event()
             before.record()
@@ -405,9 +417,9 @@ class BLSTMLayerFn(torch.autograd.Function):
                 grad_overlap.flush()       # nothing left to hide behind: go now
             for t_ in (dg, x, out, dbias_part):
                 t_.record_stream(side)
-            return (dx, None, None, None, None) + (None,) * 8
+            return (dx, None, None, None, None, None) + (None,) * 8
         gl = weight_grads()
-        return (dx, None, None, None, None, *gl)
+        return (dx, None, None, None, None, None, *gl)
 
 
 class PackedBLSTM:
@@ -454,8 +466,9 @@ def prepack_blstm_layers(layer_params, in_dims, rows=0):
     return out
 
 
-def blstm_layer(x, lengths, params, dact_y=None, sweep_follows=False, prepacked=None):
+def blstm_layer(x, lengths, params, dact_y=None, sweep_follows=False, prepacked=None, out_dropout=None):
     """sweep_follows: in the backward pass the sweep of the layer BELOW runs right after this layer's
     (True for every layer but the first) -- lets the overlapped weight-gradient GEMMs stay off its XCDs.
-    prepacked: a PackedBLSTM made from ``params`` (else packed here)."""
-    return BLSTMLayerFn.apply(x, lengths, dact_y, sweep_follows, prepacked, *params)
+    prepacked: a PackedBLSTM made from ``params`` (else packed here).
+    out_dropout = (p, seed, offset): return dropout(output) (the inter-layer dropout fused into the sweep)."""
+    return BLSTMLayerFn.apply(x, lengths, dact_y, sweep_follows, prepacked, out_dropout, *params)

@@ -375,19 +375,27 @@ import os as _os
 LSTM_FLAGS = int(_os.environ.get("PGASR_LSTM_FLAGS", "0"), 0)   # bit 0: force the write-through (cross-XCD) hand-off protocol; bits 8..: diagnostics
 
 
-def lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, fed=None, fed_need=0):
+def lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, fed=None, fed_need=0, out_drop=None, drop=None):
     """fed: int32 (2, ceil(T*B/256)) finished-tile counters of a ``gemm_x3w_feed`` that is launched AFTER this call on
-    another stream and fills ``gates`` while the sweep runs (zeroed by the caller before this call)."""
+    another stream and fills ``gates`` while the sweep runs (zeroed by the caller before this call).
+    out_drop + drop = (p, seed, offset): the sweep also writes dropout(out) -- the next layer's input -- there."""
     lib = _lib.load()
     ws = _lstm_ws(T, B, False, gates.device)
+    p, seed, offset = drop if (drop is not None and out_drop is not None) else (0.0, 0, 0)
+    if out_drop is not None:
+        _req(out_drop, torch.float32, "out_drop")
+        if out_drop.numel() != out.numel() or drop is None:
+            raise _lib.PgasrError("lstm_layer_fwd: out_drop must have out's size and come with drop = (p, seed, offset)")
+    dargs = (_p(out_drop), float(p), int(seed) & (2 ** 64 - 1), int(offset) & 0xFFFFFFFF)
     with _timed("lstm_fwd_kernel"):
         if fed is None:
-            st = lib.pgasr_lstm_layer_fwd(_p(gates), _p(out), _p(cbuf), _p(pack_f), _p(lengths), T, B, LSTM_FLAGS, _p(ws), ws.numel(), _stream())
+            st = lib.pgasr_lstm_layer_fwd(_p(gates), _p(out), _p(cbuf), _p(pack_f), _p(lengths), T, B, LSTM_FLAGS, *dargs,
+                                          _p(ws), ws.numel(), _stream())
         else:
             if fed.dtype != torch.int32 or not fed.is_cuda or fed.numel() < 2 * ((T * B + 255) // 256):
                 raise _lib.PgasrError("lstm_layer_fwd: fed must be an int32 GPU tensor of 2 * ceil(T*B/256) words")
             st = lib.pgasr_lstm_layer_fwd_fed(_p(gates), _p(out), _p(cbuf), _p(pack_f), _p(lengths), T, B, LSTM_FLAGS,
-                                              _p(fed), int(fed_need), _p(ws), ws.numel(), _stream())
+                                              _p(fed), int(fed_need), *dargs, _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_lstm_layer_fwd_fed" if fed is not None else "pgasr_lstm_layer_fwd")
     return ws
 

@@ -74,10 +74,11 @@ class Encoder(nn.Module):
         if training:                                   # nn.Dropout(), model.py:45,51
             h = Fh.DropoutFn.apply(h, self.drop.p, self.dropout_seed, self._next_drop_offset(), True)
         for l in range(3):
+            # nn.LSTM(dropout=0.3), model.py:42: the outputs of layers 0 and 1 are dropped on their way to the next layer --
+            # by the sweep itself (its storer waves write h_t and dropout(h_t))
+            od = (self.blstm.dropout, self.dropout_seed, self._next_drop_offset()) if (training and l < 2 and self.blstm.dropout > 0) else None
             h = Fh.blstm_layer(h, lengths, self._layer_params(l), dact_y=y if (l == 0 and not training) else None,
-                               sweep_follows=(l > 0), prepacked=packs[l])
-            if training and l < 2:                     # nn.LSTM(dropout=0.3), model.py:42: outputs of layers 0,1
-                h = Fh.DropoutFn.apply(h, self.blstm.dropout, self.dropout_seed, self._next_drop_offset())
+                               sweep_follows=(l > 0), prepacked=packs[l], out_dropout=od)
         return h, lengths
 
     def _next_drop_offset(self):

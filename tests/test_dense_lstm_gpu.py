@@ -276,6 +276,33 @@ def test_encoder_matches_reference_golden(golden_dir):
             assert torch.all(y[b, n:] == 0)
 
 
+def test_blstm_fused_output_dropout_equals_separate_dropout_pass():
+    """nn.LSTM's inter-layer dropout (model.py:42) written by the sweep's storer waves: the returned tensor is bit for bit
+    pgasr_dropout(output) with the same (p, seed, offset), and so are the gradients of the two formulations."""
+    from policy_gradient_asr_amd import functional as Fh, hipops
+    T, B = 37, 19
+    lens = [37] * 10 + [20] * 5 + [1] * 4
+    lstm, x, dy, lengths = _lstm_case(T, B, lens, seed=5)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0",
+             "weight_ih_l0_reverse", "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+    cfg = (0.3, 0x5EED, 7)
+    res = []
+    for fused in (False, True):
+        params = [getattr(lstm, n).detach().to(DEV).requires_grad_(True) for n in names]
+        xg = x.to(DEV).requires_grad_(True)
+        if fused:
+            y = Fh.blstm_layer(xg, lengths.to(torch.int32).to(DEV), params, out_dropout=cfg)
+        else:
+            y = Fh.DropoutFn.apply(Fh.blstm_layer(xg, lengths.to(torch.int32).to(DEV), params), *cfg)
+        y.backward(dy.to(DEV))
+        torch.cuda.synchronize()
+        res.append([y.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in params])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    keep = res[0][0] != 0
+    assert 0.6 < float(keep[:1].float().mean()) < 0.8           # p = 0.3 on the full-length frames
+
+
 def test_seq2seq_logprobs_and_grads_vs_oracle():
     from policy_gradient_asr_amd.model import Seq2Seq
     B, F, T, V = 4, 80, 60, 29
