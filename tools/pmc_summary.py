@@ -22,7 +22,7 @@ def one(pattern):
 
 def short(name):
     for key in ("lstm_fwd_kernel", "lstm_bwd_kernel", "gemm_x3w_kernel", "gemm_bf16x3_kernel", "gemm_f32_kernel", "gemm_reduce_kernel",
-                "ctc_lattice_kernel", "ctc_grad_kernel", "edit_distance_kernel"):
+                "ctc_lattice_kernel", "ctc_grad_kernel", "edit_distance_kernel", "beam_small_kernel", "stream_copy_kernel"):
         if key in name:
             return key
     return None
@@ -55,7 +55,7 @@ for k in sorted(set(fetch) | set(write)):
     kernels[k] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "launches": max(nf, nw),
                   "hbm_bytes_per_launch": int(2 * f * 1024 + w * 1024)}
 doc = {"source": "tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
-                 "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`; mean per launch; counter unit KB",
+                 "`PGASR_ALLOW_SEQUENTIAL=1 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity` (the profiler serialises kernels: sequential order of the same kernels); mean per launch; counter unit KB",
        "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM "
                      "section) -> hbm_read_bytes = 2*FETCH_SIZE*1024; WRITE_SIZE*1024 as is",
        "kernels": kernels}
