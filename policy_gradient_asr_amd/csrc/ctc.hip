@@ -24,8 +24,15 @@ constexpr int CTC_SMAX = CTC_THREADS * CTC_SPT;   // 2048
 constexpr int CTC_VMAX = 64;
 
 struct CtcWs {
-    double* alpha;     // [B][T][Smax]
-    double* beta;      // [B][T][Smax]
+    // The lattice leaves the chip as fp32 OFFSETS from the row maximum plus one fp64 maximum per row (round 2): the rows
+    // live in fp64 in LDS while the recursion runs (values reach -3000 at T = 1000, where fp32 resolves 2.4e-4), but
+    // within a row only states within ~100 of the maximum carry any posterior mass, and there an fp32 offset resolves
+    // < 1e-5.  Halves the lattice traffic of the round-1 fp64 spill (229 -> ~105 MB per step at B=32, T=1000, S=201).
+    float* alpha;      // [B][T][SP]     alpha_t(s) - amax[t]   (-inf stays -inf); SP = Smax rounded up to 64: the storer
+    float* beta;       // [B][T][SP]     beta_t(s)  - bmax[t]      writes whole 64-state groups, no bounds test per state
+    int SP;
+    double* amax;      // [B][T]         row maxima (0 for a row that is -inf everywhere)
+    double* bmax;      // [B][T]
     double* nll64;     // [B]
     int32_t* lab_off;  // [B][V+1]   offsets into lab_states, per label
     int32_t* lab_states;  // [B][Smax] odd (non-blank) states grouped by label, ascending s
@@ -34,17 +41,34 @@ struct CtcWs {
 __host__ __device__ inline size_t ctc_ws_layout(int T, int B, int V, int Smax, CtcWs* ws, char* base) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-    size_t a = take((size_t)B * T * Smax * sizeof(double));
-    size_t b = take((size_t)B * T * Smax * sizeof(double));
+    const int SP = (Smax + 63) / 64 * 64;
+    size_t a = take((size_t)B * T * SP * sizeof(float));
+    size_t b = take((size_t)B * T * SP * sizeof(float));
+    size_t am = take((size_t)B * T * sizeof(double));
+    size_t bm = take((size_t)B * T * sizeof(double));
     size_t n = take((size_t)B * sizeof(double));
     size_t lo = take((size_t)B * (V + 1) * sizeof(int32_t));
     size_t ls = take((size_t)B * Smax * sizeof(int32_t));
     if (ws) {
-        ws->alpha = (double*)(base + a); ws->beta = (double*)(base + b);
+        ws->alpha = (float*)(base + a); ws->beta = (float*)(base + b);
+        ws->amax = (double*)(base + am); ws->bmax = (double*)(base + bm); ws->SP = SP;
         ws->nll64 = (double*)(base + n); ws->lab_off = (int32_t*)(base + lo);
         ws->lab_states = (int32_t*)(base + ls);
     }
     return off;
+}
+
+// max over the 64 lanes of a wave, in all lanes: DPP row rotations + four readlanes (a butterfly of ds_bpermute pairs costs
+// six LDS-crossbar round trips, more than a lattice frame lasts)
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_max_f32_all(float m) {
+    m = fmaxf(m, dpp_f32<0x128>(m)); m = fmaxf(m, dpp_f32<0x124>(m));     // row_ror:8, :4
+    m = fmaxf(m, dpp_f32<0x122>(m)); m = fmaxf(m, dpp_f32<0x121>(m));     // row_ror:2, :1 -> every lane holds its row's maximum
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 
 // log(exp(a0)+exp(a1)+exp(a2)) with fp64 carries and fp32 transcendentals.
@@ -126,8 +150,38 @@ __global__ __launch_bounds__(CTC_THREADS + 64) void ctc_lattice_kernel(
     }
     __syncthreads();
 
-    double* out = (role == 0 ? ws.alpha : ws.beta) + (size_t)b * T * Smax;
-
+    float* out = (role == 0 ? ws.alpha : ws.beta) + (size_t)b * T * ws.SP;
+    double* outmax = (role == 0 ? ws.amax : ws.bmax) + (size_t)b * T;
+    // the storer wave's row write: maximum over the row (fixed butterfly order), then fp32 offsets
+    double m_ref = 0.0;          // the storer's current reference (refreshed every 4th row)
+    auto store_row = [&](const double* rc, int t_row, bool refresh) {
+        // Branch-free: the storer lane keeps 64-strided states in registers -- cells past S hold the -inf the rows were
+        // initialised with, and the output rows are padded to whole 64-state groups -- so the only waits are the LDS reads.
+        // (It sits at the same per-frame barrier as the compute waves: a slower storer would set the frame time.)
+        constexpr int NG = NSPT * 4;
+        const int ls = tid - CTC_THREADS;
+        const int ng = (S + 63) >> 6;           // 64-state groups that hold states (wave-uniform)
+        double v[NG];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) v[i] = rc[ls + 64 * i + 2];
+        // The reference of a row need not be its maximum, only NEAR it: offsets are formed in fp64 against whatever
+        // reference is stored with the row.  It is refreshed every 4th row (a row maximum moves by one frame's log-prob
+        // per frame, a few units; even 4 x 88 keeps the fp32 offset's resolution at 3e-5), and the wave reduction runs on
+        // fp32 DPP maxima -- so three rows out of four cost the storer four reads, four subtractions and four stores.
+        if (refresh) {
+            double ml = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < NG; ++i) ml = fmax(ml, v[i]);
+            const double mw = (double)wave_max_f32_all((float)ml);
+            m_ref = (mw == -INFINITY) ? 0.0 : mw;
+        }
+        const double m = m_ref;
+        float* o = out + (size_t)t_row * ws.SP + ls;
+#pragma unroll
+        for (int i = 0; i < NG; ++i)
+            if (i < ng) o[64 * i] = (float)(v[i] - m);
+        if (ls == 0) outmax[t_row] = m;
+    };
     if (Tb == 0) {
         if (role == 0 && tid == 0) {
             const double v = (Lb == 0) ? 0.0 : INFINITY;
@@ -150,7 +204,6 @@ __global__ __launch_bounds__(CTC_THREADS + 64) void ctc_lattice_kernel(
                 if (role == 0) { if (s <= 1) v = (double)lpt[lab[j]]; }
                 else           { if (s >= S - 2) v = (double)lpt[lab[j]]; }
                 row[0][s + 2] = v;
-                out[(size_t)t0 * Smax + s] = v;
             }
         }
     }
@@ -162,11 +215,7 @@ __global__ __launch_bounds__(CTC_THREADS + 64) void ctc_lattice_kernel(
         // its own loop (same number of barriers): nothing in this path ever waits for a store
         for (int k = 1; k < Tb; ++k) {
             ROW_BARRIER();
-            if (k >= 2) {    // row[cur] = frame t0 + (k-1)*dt, stable until the next barrier; frame t0 was stored by its writers
-                const double* rc = row[cur];
-                double* o = out + (size_t)(t0 + (k - 1) * dt) * Smax;
-                for (int s = tid - CTC_THREADS; s < S; s += 64) o[s] = rc[s + 2];
-            }
+            store_row(row[cur], t0 + (k - 1) * dt, ((k - 1) & 3) == 0);      // row[cur] = frame t0 + (k-1)*dt, stable until the next barrier
             cur ^= 1;
         }
     } else {
@@ -206,12 +255,9 @@ __global__ __launch_bounds__(CTC_THREADS + 64) void ctc_lattice_kernel(
         }
     }
 #undef ROW_BARRIER
-    if (Tb > 1) {        // the last frame's row
+    {                    // the last frame's row (the only one when Tb == 1)
         __syncthreads();
-        if (storer) {
-            double* o = out + (size_t)(t0 + (Tb - 1) * dt) * Smax;
-            for (int s = tid - CTC_THREADS; s < S; s += 64) o[s] = row[cur][s + 2];
-        }
+        if (storer) store_row(row[cur], t0 + (Tb - 1) * dt, ((Tb - 1) & 3) == 0);
     }
     if (role == 0) {
         __syncthreads();
@@ -246,22 +292,26 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const double nll = ws.nll64[b];
     if (nll != INFINITY) {
         const int S = 2 * Lb + 1;
-        const double* al = ws.alpha + ((size_t)b * T + t) * Smax;
-        const double* be = ws.beta + ((size_t)b * T + t) * Smax;
+        const float* al = ws.alpha + ((size_t)b * T + t) * ws.SP;
+        const float* be = ws.beta + ((size_t)b * T + t) * ws.SP;
+        // log occupancy of state s = (alpha offset + beta offset) + [row maxima + nll - log p]: the bracket is O(10)
+        const double cst = ws.amax[(size_t)b * T + t] + ws.bmax[(size_t)b * T + t] + nll;
         // blank occupancy: even states, all lanes, fixed butterfly order
         const float lpb = __shfl(lpv, blank, 64);
+        const float cb = (float)(cst - (double)lpb);
         float accb = 0.f;
         for (int s = 2 * lane; s < S; s += 128)
-            accb += __expf((float)(al[s] + be[s] + nll - (double)lpb));
+            accb += __expf((al[s] + be[s]) + cb);
         accb = wave_sum(accb);
         float occ = accb;
         if (lane < V && lane != blank) {
             const int32_t* lo = ws.lab_off + (size_t)b * (V + 1);
             const int32_t* ls = ws.lab_states + (size_t)b * Smax;
             float acc = 0.f;
+            const float cl = (float)(cst - (double)lpv);
             for (int i = lo[lane]; i < lo[lane + 1]; ++i) {
                 const int s = ls[i];
-                acc += __expf((float)(al[s] + be[s] + nll - (double)lpv));
+                acc += __expf((al[s] + be[s]) + cl);
             }
             occ = acc;
         }
