@@ -74,28 +74,23 @@ __device__ __forceinline__ float wave_max_f32_all(float m) {
 // log(exp(a0)+exp(a1)+exp(a2)) with fp64 carries and fp32 transcendentals.
 __device__ __forceinline__ double lse3(double a0, double a1, double a2) {
     const double m = fmax(fmax(a0, a1), a2);
-    if (m == -INFINITY) return -INFINITY;
-    const float s = __expf((float)(a0 - m)) + __expf((float)(a1 - m)) + __expf((float)(a2 - m));
+    // no branch on the all -inf row (a select at the end instead): every taken branch on the T-step chain refills the
+    // instruction buffer.  mz keeps the differences finite-or--inf when m = -inf.
+    const double mz = (m == -INFINITY) ? 0.0 : m;
+    const float s = __builtin_amdgcn_exp2f(1.4426950408889634f * (float)(a0 - mz)) + __builtin_amdgcn_exp2f(1.4426950408889634f * (float)(a1 - mz)) +
+                    __builtin_amdgcn_exp2f(1.4426950408889634f * (float)(a2 - mz));
     // s is in [1, 3]: the bare v_log_f32 (log2) needs none of __logf's denormal / range fix-ups, which sat on the chain
-    return m + (double)(0.6931471805599453f * __builtin_amdgcn_logf(s));
+    const double r = m + (double)(0.6931471805599453f * __builtin_amdgcn_logf(s));
+    return (m == -INFINITY) ? -INFINITY : r;
 }
 
-// NSPT = states per thread, a compile-time constant: the common case S <= 256 (L <= 127) runs with no per-state
-// loop or bound checks on the T-step chain (measured 492 -> see DESIGN.md at T=1000, S=201).
-template <int NSPT>
-__global__ __launch_bounds__(CTC_THREADS + 64) void ctc_lattice_kernel(
-    const float* __restrict__ lp, const int32_t* __restrict__ targets,
-    const int32_t* __restrict__ in_len, const int32_t* __restrict__ tg_len,
-    int T, int B, int V, int Lmax, int Smax, int blank, CtcWs ws, float* __restrict__ nll_out, int role_base) {
+// label -> states lists for the gradient pass (grid row y = 2 of the lattice launch)
+__device__ __forceinline__ void ctc_labels_body(const int32_t* __restrict__ targets, const int32_t* __restrict__ tg_len,
+                                                int V, int Lmax, int Smax, int blank, CtcWs ws) {
     const int b = blockIdx.x;
-    const int role = blockIdx.y + role_base;
     const int tid = threadIdx.x;
-    int Tb = in_len[b]; Tb = Tb < 0 ? 0 : (Tb > T ? T : Tb);
     int Lb = tg_len[b]; Lb = Lb < 0 ? 0 : (Lb > Lmax ? Lmax : Lb);
-    const int S = 2 * Lb + 1;
     const int32_t* tgt = targets + (size_t)b * Lmax;
-
-    if (role == 2) {
         // label -> list of odd states carrying it (ascending s).  One thread per label.
         __shared__ int cnt[CTC_VMAX + 1];
         if (tid <= V) cnt[tid] = 0;
@@ -120,8 +115,22 @@ __global__ __launch_bounds__(CTC_THREADS + 64) void ctc_lattice_kernel(
             for (int i = 0; i < Lb; ++i)
                 if (tgt[i] == tid) ws.lab_states[(size_t)b * Smax + (w++)] = 2 * i + 1;
         }
-        return;
-    }
+}
+
+// NSPT = states per thread, a compile-time constant: the common case S <= 256 (L <= 127) runs with no per-state
+// loop or bound checks on the T-step chain (measured 492 -> see DESIGN.md at T=1000, S=201).
+template <int NSPT, int ROLE>
+__device__ __forceinline__ void ctc_lattice_body(
+    const float* __restrict__ lp, const int32_t* __restrict__ targets,
+    const int32_t* __restrict__ in_len, const int32_t* __restrict__ tg_len,
+    int T, int B, int V, int Lmax, int Smax, int blank, CtcWs ws, float* __restrict__ nll_out) {
+    const int b = blockIdx.x;
+    constexpr int role = ROLE;          // compile-time: the frame loop carries no direction test
+    const int tid = threadIdx.x;
+    int Tb = in_len[b]; Tb = Tb < 0 ? 0 : (Tb > T ? T : Tb);
+    int Lb = tg_len[b]; Lb = Lb < 0 ? 0 : (Lb > Lmax ? Lmax : Lb);
+    const int S = 2 * Lb + 1;
+    const int32_t* tgt = targets + (size_t)b * Lmax;
 
     // row buffers: position p = s + 2, two guard cells of -inf on each side
     constexpr int ROW = NSPT * CTC_THREADS + 4;
@@ -242,14 +251,16 @@ __global__ __launch_bounds__(CTC_THREADS + 64) void ctc_lattice_kernel(
             double* rn = row[cur ^ 1];
 #pragma unroll
             for (int j = 0; j < NSPT; ++j) {
+                // no test on the chain: all three neighbours are read (guard cells on both sides), a state that may not
+                // skip and a thread past S select -inf
                 const int s = tid + j * CTC_THREADS;
-                if (s < S) {
-                    const int p = s + 2;
-                    double a0 = rc[p], a1, a2;
-                    if (role == 0) { a1 = rc[p - 1]; a2 = skip[j] ? rc[p - 2] : -INFINITY; }
-                    else           { a1 = rc[p + 1]; a2 = skip[j] ? rc[p + 2] : -INFINITY; }
-                    rn[p] = lse3(a0, a1, a2) + (double)lpc[j];
-                }
+                const int p = s + 2;
+                const double a0 = rc[p];
+                const double a1 = rc[role == 0 ? p - 1 : p + 1];
+                const double a2r = rc[role == 0 ? p - 2 : p + 2];
+                const double a2 = skip[j] ? a2r : -INFINITY;
+                const double v = lse3(a0, a1, a2) + (double)lpc[j];
+                rn[p] = (s < S) ? v : -INFINITY;
             }
             cur ^= 1;
         }
@@ -268,6 +279,17 @@ __global__ __launch_bounds__(CTC_THREADS + 64) void ctc_lattice_kernel(
             nll_out[b] = (float)(-ll);
         }
     }
+}
+
+template <int NSPT>
+__global__ __launch_bounds__(CTC_THREADS + 64) void ctc_lattice_kernel(
+    const float* __restrict__ lp, const int32_t* __restrict__ targets,
+    const int32_t* __restrict__ in_len, const int32_t* __restrict__ tg_len,
+    int T, int B, int V, int Lmax, int Smax, int blank, CtcWs ws, float* __restrict__ nll_out, int role_base) {
+    const int role = blockIdx.y + role_base;      // one uniform branch per workgroup, none per frame
+    if (role == 0) ctc_lattice_body<NSPT, 0>(lp, targets, in_len, tg_len, T, B, V, Lmax, Smax, blank, ws, nll_out);
+    else if (role == 1) ctc_lattice_body<NSPT, 1>(lp, targets, in_len, tg_len, T, B, V, Lmax, Smax, blank, ws, nll_out);
+    else ctc_labels_body(targets, tg_len, V, Lmax, Smax, blank, ws);
 }
 
 
