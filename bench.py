@@ -413,9 +413,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_step():
+    step_marks = []      # (start, end) events of the timed steps: with the sweeps' events they give the phases of a step
+
+    def one_step(mark=False):
         batch = feeder.next()
+        if mark:
+            e0 = torch.cuda.Event(enable_timing=True); e0.record()
         loss = trainer.step(*batch)
+        if mark:
+            e1 = torch.cuda.Event(enable_timing=True); e1.record()
+            step_marks.append((e0, e1))
         feeder.done()
         return loss
 
@@ -428,12 +435,13 @@ def main():
     hipops.profile_reset(True, only=("lstm_",))     # live HIP-event timing of the dominant kernels (6 launches a step)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = one_step()
+        loss = one_step(mark=True)
     host_enqueue_s = time.perf_counter() - t0       # how long the host needed to ENQUEUE the steps (it runs ahead of the GPU)
     barrier()
     dt_local = time.perf_counter() - t0
     if rank == 0:
         print(f"[bench] timed region: {dt_local:.3f} s for {args.steps} steps", file=sys.stderr, flush=True)
+    phases = hipops.profile_phases(step_marks)
     prof = hipops.profile_collect()
     # the other instrumented kernels (GEMMs, beam search) are timed in two extra steps OUTSIDE the timed region
     hipops.profile_reset(True)
@@ -513,6 +521,7 @@ def main():
                               "note": "whole-step dense contraction flops (SURVEY §8d: 28.65 GFLOP per 1000-frame utterance) per GPU / ms_per_step"},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
+            "phase_ms_per_step": phases,
             "loss": float(loss.item()),
         }
         if ar is not None:

@@ -104,6 +104,10 @@ int pgasr_frame_argmax_sample(const float* scores, int T, int B, int V,
  * tokens (P,B,T) int32, token_lengths (P,B) int32.  Bit-exact against
  * oracle.decode_ref.collapse_path.
  * ---------------------------------------------------------------------------------------- */
+/* A0  the collated batch of data.py:107-116 made ready for the kernels in one launch: fmask (B,T) fp32 1/0 -> in_len (B)
+ * (model.py:52: lengths = mask.sum(1)); tmask (B,L) int64 1/0 -> tg_len (B) (data.py:101); targets (B,L) int64 -> int32. */
+int pgasr_batch_prep(const float* fmask, int B, int T, const long long* tmask, const long long* targets, int L,
+                     int32_t* in_len, int32_t* tg_len, int32_t* targets32, void* stream);
 int pgasr_ctc_collapse(const int32_t* paths, const int32_t* lengths, int P, int T, int B,
                        int blank, int32_t* tokens, int32_t* token_lengths, void* stream);
 

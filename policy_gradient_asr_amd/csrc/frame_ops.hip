@@ -183,6 +183,41 @@ extern "C" int pgasr_frame_argmax_sample(const float* scores, int T, int B, int 
     return PGASR_OK;
 }
 
+namespace {
+// model.py:227-230's batch, made ready for the kernels in ONE launch: frame counts from the feature mask (model.py:52), label
+// counts from the target mask (data.py:101), targets as int32.  (As five torch ops these were ~30 us of launches in front of
+// every step's first kernel.)
+__global__ __launch_bounds__(256) void batch_prep_kernel(const float* __restrict__ fmask, int T, const long long* __restrict__ tmask,
+                                                         const long long* __restrict__ targets, int L, int32_t* __restrict__ in_len,
+                                                         int32_t* __restrict__ tg_len, int32_t* __restrict__ targets32) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float fs = 0.f; int ts = 0;
+    for (int t = tid; t < T; t += 256) fs += fmask[(size_t)b * T + t];
+    for (int i = tid; i < L; i += 256) {
+        ts += (int)tmask[(size_t)b * L + i];
+        targets32[(size_t)b * L + i] = (int32_t)targets[(size_t)b * L + i];
+    }
+    fs = wave_sum(fs);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ts += __shfl_xor(ts, o, 64);
+    __shared__ float sf[4]; __shared__ int si[4];
+    if (lane == 0) { sf[wid] = fs; si[wid] = ts; }
+    __syncthreads();
+    if (tid == 0) {
+        in_len[b] = (int32_t)((sf[0] + sf[1]) + (sf[2] + sf[3]));       // mask entries are 0/1: exact in fp32 up to 2^24 frames
+        tg_len[b] = (si[0] + si[1]) + (si[2] + si[3]);
+    }
+}
+}  // namespace
+
+extern "C" int pgasr_batch_prep(const float* fmask, int B, int T, const long long* tmask, const long long* targets, int L,
+                                int32_t* in_len, int32_t* tg_len, int32_t* targets32, void* stream) {
+    if (!fmask || !tmask || !targets || !in_len || !tg_len || !targets32 || B <= 0 || T <= 0 || L <= 0) return PGASR_ERR_INVALID_ARG;
+    PGASR_LAUNCH_KERNEL(batch_prep_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, fmask, T, tmask, targets, L, in_len, tg_len, targets32);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
+
 extern "C" int pgasr_ctc_collapse(const int32_t* paths, const int32_t* lengths, int P, int T, int B,
                                   int blank, int32_t* tokens, int32_t* token_lengths, void* stream) {
     if (!paths || !tokens || !token_lengths || P <= 0 || T <= 0 || B <= 0) return PGASR_ERR_INVALID_ARG;

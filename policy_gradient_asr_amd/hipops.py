@@ -55,6 +55,28 @@ def profile_collect():
     return out
 
 
+def profile_phases(step_marks):
+    """Mean phases of a train step from the HIP events of its six sweeps (``profile_reset(True, only=("lstm_",))``) and one
+    (start, end) event pair per step, all on the main stream: front end (step start -> first forward sweep), forward (first
+    forward sweep start -> last forward sweep end, gaps included), loss section (-> first backward sweep), backward sweeps, tail
+    (last backward sweep end -> end of the step's Adam).  Synchronises."""
+    torch.cuda.synchronize()
+    sweeps = [(n, a, b) for n, a, b in _prof_events if n.startswith("lstm_")]
+    if not step_marks or len(sweeps) != 6 * len(step_marks):
+        return None
+    acc = {"front_end": 0.0, "forward_sweeps": 0.0, "loss_section": 0.0, "backward_sweeps": 0.0, "tail": 0.0}
+    for i, (s0, s1) in enumerate(step_marks):
+        sw = sweeps[6 * i:6 * i + 6]
+        if [n for n, _, _ in sw] != ["lstm_fwd_kernel"] * 3 + ["lstm_bwd_kernel"] * 3:
+            return None
+        acc["front_end"] += s0.elapsed_time(sw[0][1])
+        acc["forward_sweeps"] += sw[0][1].elapsed_time(sw[2][2])
+        acc["loss_section"] += sw[2][2].elapsed_time(sw[3][1])
+        acc["backward_sweeps"] += sw[3][1].elapsed_time(sw[5][2])
+        acc["tail"] += sw[5][2].elapsed_time(s1)
+    return {k: v / len(step_marks) for k, v in acc.items()}
+
+
 class _timed:
     def __init__(self, name):
         self.name = name
@@ -178,6 +200,22 @@ def frame_argmax_sample(scores, seed=0, offset=0, want_greedy=True, want_sample=
                                        _p(g), _p(s), _stream())
     _lib.check(st, "pgasr_frame_argmax_sample")
     return g, s
+
+
+def batch_prep(fmask, tmask, targets):
+    """The collated batch (model.py:227-230) -> (in_len (B) int32, tg_len (B) int32, targets (B,L) int32) in one launch."""
+    lib = _lib.load()
+    _req(fmask, torch.float32, "fmask"); _req(tmask, torch.int64, "tmask"); _req(targets, torch.int64, "targets")
+    B, T = fmask.shape
+    L = targets.shape[1]
+    if tuple(tmask.shape) != (B, L) or targets.shape[0] != B:
+        raise _lib.PgasrError("batch_prep: fmask (B,T), tmask (B,L), targets (B,L)")
+    dev = fmask.device
+    in_len = torch.empty(B, dtype=torch.int32, device=dev)
+    tg_len = torch.empty(B, dtype=torch.int32, device=dev)
+    tg32 = torch.empty(B, L, dtype=torch.int32, device=dev)
+    _lib.check(lib.pgasr_batch_prep(_p(fmask), B, T, _p(tmask), _p(targets), L, _p(in_len), _p(tg_len), _p(tg32), _stream()), "pgasr_batch_prep")
+    return in_len, tg_len, tg32
 
 
 def ctc_collapse(paths, lengths, blank=0, out=None):

@@ -40,37 +40,39 @@ class PGCTCLossFn(torch.autograd.Function):
     policy_grad.rewards_all_t, and the gradient uses their sum (one coefficient per utterance).
     Returns (loss, stats) where stats = (nll (B), R_s (B), R_g (B)) detached."""
 
-    _lattice_streams = {}      # one lattice stream per calling stream
-
+    _lattice_streams = {}      # one side stream per calling stream
+    unit_grad = False          # set by the trainer around loss.backward(): the incoming gradient is exactly 1, skip the multiply
     @staticmethod
     def forward(ctx, logits, in_len, targets, tg_len, lam, seed, offset, global_batch, blank, beam=0):
         T, B, V = logits.shape
         dev = logits.device
         lp = hipops.log_softmax_rows(logits.contiguous())
-        # The alpha/beta lattice (a 64-workgroup serial chain, ~0.5 ms at T=1000) needs only lp and the targets: it runs
-        # on a side stream beside sampling, collapse, edit distance and the reward arithmetic, which the gradient pass
-        # then joins.
+        # The alpha/beta lattice (96 workgroups, a serial chain of T frames, ~0.27 ms at T=1000) is the long pole of this
+        # section and stays on the CALLING stream; sampling, collapse, (beam search,) edit distance and the reward
+        # arithmetic (~0.13 ms with the greedy baseline) run beside it on a side stream and are joined before the gradient
+        # pass.  (Round 1 had it the other way round: two cross-stream hops then sat on the critical chain.)
         main = torch.cuda.current_stream()
         side = PGCTCLossFn._lattice_streams.setdefault(main.cuda_stream, None) or torch.cuda.Stream()
         PGCTCLossFn._lattice_streams[main.cuda_stream] = side
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            nll, lattice = hipops.ctc_lattice(lp, targets, in_len, tg_len, blank=blank)
-        if beam > 0:
-            # baseline hypothesis = prefix beam search + collapse_fn (policy_grad.py:6-8), rows [0] of the pair buffers
-            _, sample = hipops.frame_argmax_sample(lp, seed=seed, offset=offset, want_greedy=False)
-            tokens = torch.zeros(2, B, T, dtype=torch.int32, device=dev)
-            tok_len = torch.empty(2, B, dtype=torch.int32, device=dev)
-            hipops.ctc_beam_search(lp, in_len, beam=beam, blank=blank, collapse=True, out=(tokens[0], tok_len[0]))
-            hipops.ctc_collapse(sample[None], in_len, blank=blank, out=(tokens[1:], tok_len[1:]))
-        else:
-            greedy, sample = hipops.frame_argmax_sample(lp, seed=seed, offset=offset)
-            paths = torch.stack((greedy, sample), dim=0)                          # (2,T,B)
-            tokens, tok_len = hipops.ctc_collapse(paths, in_len, blank=blank)     # (2,B,T), (2,B)
-        dist = hipops.edit_distance(targets.repeat(2, 1), tg_len.repeat(2), tokens.view(2 * B, T), tok_len.view(2 * B))
-        R_g, R_s, coef, utt_scale = hipops.pg_rewards(dist, tg_len, lam, 1.0 / float(global_batch))
+            if beam > 0:
+                # baseline hypothesis = prefix beam search + collapse_fn (policy_grad.py:6-8), rows [0] of the pair buffers
+                _, sample = hipops.frame_argmax_sample(lp, seed=seed, offset=offset, want_greedy=False)
+                tokens = torch.zeros(2, B, T, dtype=torch.int32, device=dev)
+                tok_len = torch.empty(2, B, dtype=torch.int32, device=dev)
+                hipops.ctc_beam_search(lp, in_len, beam=beam, blank=blank, collapse=True, out=(tokens[0], tok_len[0]))
+                hipops.ctc_collapse(sample[None], in_len, blank=blank, out=(tokens[1:], tok_len[1:]))
+            else:
+                greedy, sample = hipops.frame_argmax_sample(lp, seed=seed, offset=offset)
+                paths = torch.stack((greedy, sample), dim=0)                          # (2,T,B)
+                tokens, tok_len = hipops.ctc_collapse(paths, in_len, blank=blank)     # (2,B,T), (2,B)
+            dist = hipops.edit_distance(targets.repeat(2, 1), tg_len.repeat(2), tokens.view(2 * B, T), tok_len.view(2 * B))
+            R_g, R_s, coef, utt_scale = hipops.pg_rewards(dist, tg_len, lam, 1.0 / float(global_batch))
+        nll, lattice = hipops.ctc_lattice(lp, targets, in_len, tg_len, blank=blank)
         main.wait_stream(side)
-        nll.record_stream(main)
+        for t_ in (sample, R_g, R_s, coef, utt_scale):
+            t_.record_stream(main)
         grad = hipops.ctc_grad_from_lattice(lp, in_len, tg_len, lattice, utt_scale=utt_scale, pg_coef=coef, pg_path=sample)
         loss = hipops.pg_loss_value(lp, sample, in_len, nll, utt_scale, coef).sum()
         ctx.save_for_backward(grad)
@@ -81,7 +83,7 @@ class PGCTCLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, *unused):
         (grad,) = ctx.saved_tensors
-        return grad * g, None, None, None, None, None, None, None, None, None
+        return (grad if PGCTCLossFn.unit_grad else grad * g), None, None, None, None, None, None, None, None, None
 
 
 def pg_ctc_loss(logits, in_len, targets, tg_len, lam=1.0, seed=0, offset=0, global_batch=None, blank=0, beam=0):

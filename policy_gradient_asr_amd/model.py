@@ -57,11 +57,12 @@ class Encoder(nn.Module):
                 out.append(getattr(self.blstm, f"{k}_l{l}{sfx}"))
         return out
 
-    def forward_time_major(self, x, mask):
-        """x (B,F,T), mask (B,T) -> (T,B,512) and int32 lengths."""
+    def forward_time_major(self, x, mask, lengths=None):
+        """x (B,F,T), mask (B,T) -> (T,B,512) and int32 lengths (``lengths``: mask.sum(1) already on the device as int32)."""
         if not x.is_cuda:
             raise RuntimeError("policy_gradient_asr_amd.Encoder runs on the MI355X only (no CPU fallback)")
-        lengths = mask.sum(dim=1).to(torch.int32).contiguous()   # stays on the device: no host sync
+        if lengths is None:
+            lengths = mask.sum(dim=1).to(torch.int32).contiguous()   # stays on the device: no host sync
         training = self.training
         # weight repacking (gate-permuted W_ih, its bf16 planes, the register-resident W_hh packs) depends on the
         # parameters only: all three layers' packs are made on a side stream while the front end runs
@@ -120,9 +121,9 @@ class Seq2Seq(nn.Module):
         self.encoder = Encoder(n_feats=n_feats)
         self.head = nn.Linear(2 * HID, alphabet_size)
 
-    def logits(self, x, fmask):
+    def logits(self, x, fmask, lengths=None):
         """(T,B,V) pre-softmax scores and int32 lengths -- what the fused loss consumes."""
-        h, lengths = self.encoder.forward_time_major(x, fmask)
+        h, lengths = self.encoder.forward_time_major(x, fmask, lengths)
         return Fh.LinearFn.apply(h, self.head.weight, self.head.bias), lengths
 
     def forward(self, x, t, fmask, device=None):

@@ -263,3 +263,16 @@ def test_reinforce_grad_vs_oracle(ops, dev):
     acc = torch.ones(T, B, V, device=dev)
     ops.reinforce_grad(*(torch.from_numpy(x).to(dev) for x in (scores, path, coef, lens)), out=acc, accumulate=True)
     np.testing.assert_allclose(acc.cpu().numpy(), want + 1.0, rtol=1e-4, atol=1e-6)
+
+
+def test_batch_prep_matches_torch(ops, dev):
+    """fmask / tmask / targets of the collate_custom batch -> lengths and int32 targets in one launch."""
+    g = torch.Generator().manual_seed(5)
+    B, T, L = 7, 333, 41
+    lens = torch.randint(0, T + 1, (B,), generator=g); tl = torch.randint(0, L + 1, (B,), generator=g)
+    fmask = (torch.arange(T)[None, :] < lens[:, None]).float()
+    tmask = (torch.arange(L)[None, :] < tl[:, None]).long()
+    targets = torch.randint(1, 29, (B, L), generator=g) * tmask
+    in_len, tg_len, tg32 = ops.batch_prep(fmask.to(dev), tmask.to(dev), targets.to(dev))
+    assert in_len.dtype == tg_len.dtype == tg32.dtype == torch.int32
+    assert torch.equal(in_len.cpu(), lens.int()) and torch.equal(tg_len.cpu(), tl.int()) and torch.equal(tg32.cpu(), targets.int())
