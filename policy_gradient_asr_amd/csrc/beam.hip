@@ -305,7 +305,7 @@ inline size_t beam_lds_bytes(int K, int V) {
 //     17 mantissa bits replaced by [first-touch order of the reference's loop nest (:68,:74), slot, entry]: descending
 //     key order IS the reference's stable sort (:110-113).  Each lane sorts its 8 keys with a 19-exchange network in
 //     registers; K rounds of (row all-reduce max by DPP rotations on the high words, 4 readlanes, rarely a second pass
-//     on the low words) pop the winners in rank order; a lane's list beyond head/next waits in LDS.
+//     on the low words) pop the winners in rank order (a pop shifts the winner lane's register list).
 //   frames are staged 32 at a time through LDS, two chunks ahead in registers, so no load is ever waited for.
 // =====================================================================================================================
 namespace sb {
@@ -315,9 +315,8 @@ constexpr unsigned ROOT = 0x8000u, NONE = 0xFFFFu, BAD_ID = 0x0FFFFFFFu;
 constexpr unsigned KEYMASK = 0x01FFFFFFu;
 constexpr size_t LDS_TABLE = (size_t)H * 4;          // 128 KB
 constexpr size_t LDS_FRAMES = (size_t)2 * CH * V_MAX * 4;
-constexpr size_t LDS_LIST = (size_t)6 * 64 * 8;
 constexpr size_t LDS_MM = 64;
-constexpr size_t LDS_BYTES = LDS_TABLE + LDS_FRAMES + LDS_LIST + LDS_MM;
+constexpr size_t LDS_BYTES = LDS_TABLE + LDS_FRAMES + LDS_MM;
 
 __device__ __forceinline__ double lse2f(double a, double b) {
     // 1 + e^x with x <= 0 is in [1, 2]: the bare v_exp_f32 / v_log_f32 (base 2) need none of the library forms' range fix-ups
@@ -355,8 +354,7 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* table = reinterpret_cast<unsigned*>(smem);
     float* frames = reinterpret_cast<float*>(smem + LDS_TABLE);
-    unsigned long long* lst = reinterpret_cast<unsigned long long*>(smem + LDS_TABLE + LDS_FRAMES);
-    unsigned* mm = reinterpret_cast<unsigned*>(smem + LDS_TABLE + LDS_FRAMES + LDS_LIST);
+    unsigned* mm = reinterpret_cast<unsigned*>(smem + LDS_TABLE + LDS_FRAMES);
     const int b = blockIdx.x, lane = threadIdx.x, q = lane >> 4, j = lane & 15;
     int Tb = lengths ? lengths[b] : T; Tb = Tb < 0 ? 0 : (Tb > T ? T : Tb);
 
@@ -403,11 +401,10 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
             if (par == ROOT) pidx = root_pos;
             else if (par != NONE) pidx = (int)((table[par] >> 25) & 31u) - 1;
         }
+        // DS operations of one wave execute in issue order: zero, atomic-or and read need no wait between them
         if (lane < 16) mm[lane] = 0u;
-        __syncthreads();
         if (lane < nb && pidx >= 0) atomicOr(&mm[pidx], 1u << last);
-        __syncthreads();
-        const unsigned mmask = mm[j];
+        const unsigned mmask = __hip_atomic_load(&mm[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 
         const int src = pidx >= 0 ? pidx : 0;
         const double pb_i = __shfl(pb, src, 16), tot_i = __shfl(tot, src, 16);
@@ -429,7 +426,9 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
         const double sstay = lse2f(npb, npnb);
 
         // ---- the 8 candidates of this lane as keys ----
-        const double tot0 = __shfl(tot, 0, 64);
+        const long long tb0 = __double_as_longlong(tot);
+        const double tot0 = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(tb0 >> 32), 0) << 32) |
+                                                 (unsigned)__builtin_amdgcn_readlane((int)(unsigned)tb0, 0));
         const double ref = (tot0 == -INFINITY) ? 0.0 : tot0;
         unsigned long long k[8];
 #pragma unroll
@@ -453,15 +452,14 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
         SB_CE(1, 4) SB_CE(3, 6)
         SB_CE(2, 4) SB_CE(3, 5)
         SB_CE(3, 4)
-#pragma unroll
-        for (int d = 0; d < 6; ++d) lst[d * 64 + lane] = k[d + 2];
-        unsigned long long head = k[0], next = k[1];
-        int ptr = 0;
+        // the lane's sorted list stays in registers; a pop shifts it (14 v_mov under a one-lane exec mask: no LDS round trip,
+        // no wait on the K-round chain)
 
         // ---- K rounds: pop the winners in rank order ----
         unsigned packed = 0u;
         int nnew = 0;
         for (int r = 0; r < K; ++r) {
+            const unsigned long long head = k[0];
             const unsigned hh = (unsigned)(head >> 32);
             const unsigned smax = wave_allmax(hh);
             if (smax == 0u) break;
@@ -476,9 +474,9 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
             const unsigned pk = ((unsigned)(wl >> 4) << 7) | (wlo & 0x7Fu);
             if (j == r) packed = pk;
             if (lane == wl) {
-                head = next;
-                next = (ptr < 6) ? lst[ptr * 64 + lane] : 0ull;
-                ++ptr;
+#pragma unroll
+                for (int d = 0; d < 7; ++d) k[d] = k[d + 1];
+                k[7] = 0ull;
             }
             ++nnew;
         }
@@ -529,7 +527,6 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
             id = n_id;
         } else { pb = pnb = tot = -INFINITY; last = -1; par = NONE; id = BAD_ID; }
         nb = nnew;
-        __syncthreads();
     }
 
     // ---- result: ancestors of the best entry, in order, optionally through collapse_fn ----
