@@ -353,6 +353,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
 
+    # Rank 0 prints ONE JSON line on stdout -- and nothing else may: RCCL writes its version banner to stdout from C when a
+    # communicator is created (every rank would add five lines to the driver's capture).  File descriptor 1 is pointed at
+    # stderr for the whole run; the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -366,11 +373,17 @@ def main():
         local_rank = 0
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    # plumbing rehearsal for a one-GPU box (never used by the driver): a 1-rank RCCL group whose all-reduces (identities)
+    # are really issued, buckets, stream and event waits included -- what a collective stream does to the step's own streams
+    # can be seen without a second GPU
+    solo_collective = world == 1 and os.environ.get("PGASR_BENCH_SOLO_COLLECTIVE", "") == "1"
     if world > 1:
         if rehearse:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    elif solo_collective:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
 
     from policy_gradient_asr_amd import hipops
     if rehearse:
@@ -385,6 +398,8 @@ def main():
     bucketed = args.workload == "bucketed"
     trainer = PolicyGradientTrainer(model, lr=5e-4, lam=1.0, seed=1234, world_size=world, rank=rank,
                                     **({"reward_decoder": "beam", "beam_size": 16} if bucketed else {}))
+    if solo_collective:
+        trainer.collective = True
     # a silently slower configuration (feed-ahead fallen back to the sequential order because kernels of different
     # streams do not overlap here) must not be benchmarked unnoticed; counter-collecting profiler passes serialise
     # kernels by design and say so with PGASR_ALLOW_SEQUENTIAL=1
@@ -530,9 +545,12 @@ def main():
             out["max_rel_err_vs_fp64"] = parity_vs_fp64(model, trainer, [t.to(dev) for t in host[0]])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
+        dist.destroy_process_group()
+    elif solo_collective:
         dist.destroy_process_group()
 
 

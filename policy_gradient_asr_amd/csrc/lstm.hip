@@ -103,9 +103,11 @@ struct LstmArgs {
 // Diagnostic build: wave 0 of every workgroup accumulates, in registers, the cycles between consecutive stamps (segment
 // ending at `slot`); one store per workgroup at the end (member 5 of cluster 0 is read by tools/dev/tools_stamps.py).  No memory
 // traffic in the loop: per-step stores of the stamps sat in front of the wave's next s_waitcnt vmcnt(0) and distorted the picture.
-#define STAMP_DECL long long st_last_ = clock64(); long long st_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP_DECL long long st_last_ = clock64(); long long st_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+                   const long long st_c0_ = clock64(), st_r0_ = wall_clock64()
 #define STAMP(slot) do { if (w == 0) { const long long now_ = clock64(); st_acc_[slot] += now_ - st_last_; st_last_ = now_; } } while (0)
-#define STAMP_FLUSH() do { if (g == 5 && bg == 0 && dir == 0 && tid == 0) { for (int i_ = 0; i_ < 8; ++i_) a.stamps[i_] = st_acc_[i_]; } } while (0)
+#define STAMP_FLUSH() do { if (g == 5 && bg == 0 && dir == 0 && tid == 0) { for (int i_ = 0; i_ < 8; ++i_) a.stamps[i_] = st_acc_[i_]; \
+                           a.stamps[8] = clock64() - st_c0_; a.stamps[9] = wall_clock64() - st_r0_; } } while (0)
 #else
 #define STAMP_DECL
 #define STAMP_FLUSH() do { } while (0)

@@ -99,8 +99,13 @@ class DataParallelStep:
         Every rank must call it at the same point of its step (collectives are matched by order)."""
         if not self.collective or self._early is not None:
             return
-        work = dist.all_reduce(self.gflat[split:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        self._early = (split, work)
+        # The blocking form on purpose: issued under the weight-gradient side stream it makes only THAT stream wait for the
+        # collective (the caller's stream joins the side stream before Adam anyway).  With async_op=True the whole step ran
+        # 9.0 -> 12.6 ms on a 1-rank RCCL group -- every phase slower, forward sweeps of the next step included, host enqueue
+        # time unchanged (bench.py, PGASR_BENCH_SOLO_COLLECTIVE=1); a dummy kernel in the same place and the blocking
+        # form both cost nothing.
+        dist.all_reduce(self.gflat[split:], op=dist.ReduceOp.SUM, group=self.pg)
+        self._early = (split, None)
 
     def reduce_rest(self):
         if not self.collective:

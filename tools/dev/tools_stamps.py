@@ -32,7 +32,9 @@ for r in range(4):
     print([f"se{(int(v) >> 13) & 7}.sh{(int(v) >> 12) & 1}.cu{(int(v) >> 8) & 15}" for v in hw[r].tolist()])
     ids = [int(v) >> 8 for v in hw[r].tolist()]
     print("   distinct CUs:", len(set(ids)), "of", len(ids))
-st = ws[nb - 4096 * 64: nb].view(torch.int64)[:8].cpu().double() / T
+raw = ws[nb - 4096 * 64: nb].view(torch.int64)[:10].cpu().double()
+print(f"in-kernel clock: {float(raw[8]) / float(raw[9]) * 100:.0f} MHz  (s_memtime ticks / s_memrealtime ticks x 100 MHz over the whole sweep)")
+st = raw[:8] / T
 names = {0: "loop top (loader section, progress word)", 1: "poll: h_{t-1} words valid", 2: "MFMA + partial write", 3: "LDS barrier",
          4: "LDS reads + 4-way sum", 5: "cell math + publish", 6: "result staging (LDS writes)"}
 print(f"cycles per step: {float(st.sum()):.0f}  (flags {hipops.LSTM_FLAGS:#x})")
