@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from policy_gradient_asr_amd import hipops
 dev = torch.device("cuda:0")
-T, B = 1000, 32
+T, B = 1000, int(os.environ.get("SWEEP_B", "32"))
 g = torch.Generator().manual_seed(0)
 params = []
 for d in range(2):
