@@ -210,8 +210,12 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_x3w_kernel(DmaGemmArgs g) {
     // (339 / 285); 4 waves of 128x64 with the split hand-placed in the MFMA shadows (382 / 270); 4 dedicated loader
     // waves beside the 8 compute waves (308 / 265).  rocprof (profiles/r01_gemm_pmc.txt): no LDS bank conflicts, MFMA
     // pipe 35 % busy, VALU 28 %, per k-tile the CU moves 48 KB by DMA and 128 KB of fragment reads through LDS -- MFMA,
-    // LDS, VALU and the load path are all within 2x of each other, so no single reordering wins; the next step is a
-    // bf16-plane activation format written by the producers (pure bf16 GEMM over 3K, 128x64 per wave).
+    // LDS, VALU and the load path are all within 2x of each other, so no single reordering wins.  Round 2 measured the
+    // "bf16-plane activation format" idea in isolation: with A arriving as hi / lo planes too (same tile, same stages,
+    // fragments straight from LDS into the MFMA, no v_cvt on the path; bit-identical results) the two shapes took
+    // 276 / 223 us against 286 / 243 us in the same process -- 4-8 %, not enough to pay for producers (sweep storer
+    // waves, dropout) writing two planes instead of one fp32 row.  The split was not what the MFMA pipe waits for; the
+    // per-k-tile barrier and the 128 KB of fragment reads per k-tile are.
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     f32x16 total[2][2];
 #pragma unroll

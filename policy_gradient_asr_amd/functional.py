@@ -26,7 +26,7 @@ class grad_overlap:
     straight into the parameters' pre-allocated .grad buffers.  ``finish()`` makes the current
     stream wait for the side stream; call it after loss.backward()."""
     enabled = False
-    confine = True     # keep side-stream GEMMs off the XCDs of the concurrent LSTM sweep
+    confine = os.environ.get("PGASR_CONFINE", "1") != "0"     # keep side-stream GEMMs off the XCDs of the concurrent LSTM sweep
     _sides = {}        # one side stream and one pending list PER main stream (micro-batches run on their own streams)
     _pendings = {}     # (ready event, closure) of the layer above, issued right AFTER the next sweep is launched
 

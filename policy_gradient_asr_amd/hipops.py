@@ -65,6 +65,7 @@ def profile_phases(step_marks):
     if not step_marks or len(sweeps) != 6 * len(step_marks):
         return None
     acc = {"front_end": 0.0, "forward_sweeps": 0.0, "loss_section": 0.0, "backward_sweeps": 0.0, "tail": 0.0}
+    per_sweep = [0.0] * 6      # launch order: forward layers 1..3, backward layers 3..1
     for i, (s0, s1) in enumerate(step_marks):
         sw = sweeps[6 * i:6 * i + 6]
         if [n for n, _, _ in sw] != ["lstm_fwd_kernel"] * 3 + ["lstm_bwd_kernel"] * 3:
@@ -74,7 +75,11 @@ def profile_phases(step_marks):
         acc["loss_section"] += sw[2][2].elapsed_time(sw[3][1])
         acc["backward_sweeps"] += sw[3][1].elapsed_time(sw[5][2])
         acc["tail"] += sw[5][2].elapsed_time(s1)
-    return {k: v / len(step_marks) for k, v in acc.items()}
+        for j in range(6):
+            per_sweep[j] += sw[j][1].elapsed_time(sw[j][2])
+    out = {k: v / len(step_marks) for k, v in acc.items()}
+    out["sweeps_in_launch_order"] = [v / len(step_marks) for v in per_sweep]
+    return out
 
 
 class _timed:
