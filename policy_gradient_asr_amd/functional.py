@@ -5,6 +5,7 @@ import os
 import torch
 
 from . import hipops
+from . import streams
 
 HID = hipops.HID
 FEED_AHEAD = os.environ.get("PGASR_FEED_AHEAD", "1") != "0"   # input projections run beside the forward sweeps they feed
@@ -38,7 +39,7 @@ class grad_overlap:
     def side_stream(cls):
         k = cls._key()
         if k not in cls._sides:
-            cls._sides[k] = torch.cuda.Stream()
+            cls._sides[k] = streams.side_stream("weight_gradients")
         return cls._sides[k]
 
     upper_grads_hook = None   # callable(swept_event): called by the FIRST layer's backward once every gradient above it is issued
@@ -50,7 +51,7 @@ class grad_overlap:
     def second_side_stream(cls):
         k = cls._key()
         if k not in cls._sides2:
-            cls._sides2[k] = torch.cuda.Stream()
+            cls._sides2[k] = streams.side_stream("feed")
         return cls._sides2[k]
 
     @classmethod
@@ -211,7 +212,7 @@ class LinearFn(torch.autograd.Function):
                 hipops.colsum(dy2, rows, N, N, bg, accumulate=True)
             grad_overlap.pending().append((done, weight_grads))
             side = grad_overlap.side_stream()
-            dy2.record_stream(side); x2.record_stream(side)
+            streams.hold(dy2, side); streams.hold(x2, side)
             return dx.view(ctx.shp), None, None
         dW = torch.empty(N, K, dtype=torch.float32, device=dy.device)
         hipops.gemm(dy2, x2, dW, M=N, N=K, K=rows, transA=True, lda=N, splitk=_pick_splitk(N, K, rows))
@@ -279,7 +280,7 @@ class BLSTMLayerFn(torch.autograd.Function):
                 hipops.stream_gate(busy)
                 hipops.gemm_x3w_feed(x, prepacked.planes, gates, T * B, G, I, bias_perm, busy, done)
             for t_ in (x, gates, done, bias_perm) + tuple(prepacked.planes):
-                t_.record_stream(side)
+                streams.hold(t_, side)
             main.wait_stream(side)
         else:
             if x3w:
@@ -324,7 +325,7 @@ class BLSTMLayerFn(torch.autograd.Function):
             busy = hipops.lstm_busy_ptr(T, B, True, dev)
             grad_overlap.flush(busy, launched_after=before, first=(lambda: rec["launch"](busy)) if rec is not None else None)
             if rec is not None:
-                dout.record_stream(grad_overlap.side_stream())
+                streams.hold(dout, grad_overlap.side_stream())
             swept = torch.cuda.Event()
             swept.record()
             if not ctx.sweep_follows and grad_overlap.upper_grads_hook is not None:
@@ -350,7 +351,7 @@ class BLSTMLayerFn(torch.autograd.Function):
                 hipops.gemm_x3w_feed(dg, planes_t, dx, T * B, I, G, None, busy_ptr, done, order=1)
                 side_ = torch.cuda.current_stream()
                 for t_ in (dg, dx, done) + tuple(planes_t):
-                    t_.record_stream(side_)
+                    streams.hold(t_, side_)
             grad_overlap._deferred[dx.data_ptr()] = {"dx": dx, "done": done, "need": I // 256, "drop": None, "launch": launch}
         elif ctx.needs_input_grad[0]:
             dx = torch.empty(T, B, I, dtype=torch.float32, device=dev)
@@ -379,8 +380,8 @@ class BLSTMLayerFn(torch.autograd.Function):
                 with torch.cuda.stream(hh_stream):
                     dwhh = hh()
                     for t_ in (dg, out):
-                        t_.record_stream(hh_stream)
-                dwhh.record_stream(cur)
+                        streams.hold(t_, hh_stream)
+                streams.hold(dwhh, cur)
             dwih = torch.empty(G, I, dtype=torch.float32, device=dev)
             hipops.gemm(dg, x, dwih, M=G, N=I, K=T * B, transA=True, lda=G,
                         splitk=_pick_splitk(G, I, T * B, 512 if ctx.sweep_follows else 256))    # first layer: three GEMMs share the chip in the tail -> fewer, longer slabs (0.86 -> 0.83 ms); by layer, not by mode, so that overlap on/off give the same bits
@@ -416,7 +417,7 @@ class BLSTMLayerFn(torch.autograd.Function):
             if tail:
                 grad_overlap.flush()       # nothing left to hide behind: go now
             for t_ in (dg, x, out, dbias_part):
-                t_.record_stream(side)
+                streams.hold(t_, side)
             return (dx, None, None, None, None, None) + (None,) * 8
         gl = weight_grads()
         return (dx, None, None, None, None, None, *gl)
@@ -453,7 +454,7 @@ def prepack_blstm_layers(layer_params, in_dims, rows=0):
         words = 2 * ((rows + 255) // 256)
         counters = torch.zeros(2 * nl, max(words, 1), dtype=torch.int32, device=layer_params[0][0].device) if rows > 0 else None
         if counters is not None:
-            counters.record_stream(main)
+            streams.hold(counters, main)
         for li, (params, in_dim) in enumerate(zip(layer_params, in_dims)):
             pk = prepack_blstm(params, in_dim)
             if counters is not None:
@@ -461,7 +462,7 @@ def prepack_blstm_layers(layer_params, in_dims, rows=0):
             pk.ready = torch.cuda.Event()
             pk.ready.record()
             for t in (pk.wih_perm, pk.bias_perm, pk.pack_f, pk.pack_b) + (pk.planes or ()) + (pk.planes_t or ()):
-                t.record_stream(main)
+                streams.hold(t, main)
             out.append(pk)
     return out
 

@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import hipops
+from . import streams
 
 
 class customNLLLoss(nn.Module):
@@ -52,7 +53,7 @@ class PGCTCLossFn(torch.autograd.Function):
         # arithmetic (~0.13 ms with the greedy baseline) run beside it on a side stream and are joined before the gradient
         # pass.  (Round 1 had it the other way round: two cross-stream hops then sat on the critical chain.)
         main = torch.cuda.current_stream()
-        side = PGCTCLossFn._lattice_streams.setdefault(main.cuda_stream, None) or torch.cuda.Stream()
+        side = PGCTCLossFn._lattice_streams.setdefault(main.cuda_stream, None) or streams.side_stream("loss_section")
         PGCTCLossFn._lattice_streams[main.cuda_stream] = side
         side.wait_stream(main)
         with torch.cuda.stream(side):
@@ -72,7 +73,7 @@ class PGCTCLossFn(torch.autograd.Function):
         nll, lattice = hipops.ctc_lattice(lp, targets, in_len, tg_len, blank=blank)
         main.wait_stream(side)
         for t_ in (sample, R_g, R_s, coef, utt_scale):
-            t_.record_stream(main)
+            streams.hold(t_, main)
         grad = hipops.ctc_grad_from_lattice(lp, in_len, tg_len, lattice, utt_scale=utt_scale, pg_coef=coef, pg_path=sample)
         loss = hipops.pg_loss_value(lp, sample, in_len, nll, utt_scale, coef).sum()
         ctx.save_for_backward(grad)

@@ -127,6 +127,13 @@ class DataParallelStep:
         loss.backward()
 
     def step(self, *batch):
+        from . import streams
+        # every side stream of the step is joined into the calling stream by the time backward() returns, so tensors that
+        # cross streams are kept alive until the next step begins instead of being handed to record_stream (streams.hold)
+        with streams.managed_step():
+            return self._step(*batch)
+
+    def _step(self, *batch):
         local_b = batch[0].shape[0]
         self.gflat.zero_()
         loss = self.forward_loss(batch, local_b * self.world)
@@ -184,7 +191,8 @@ class PolicyGradientTrainer(DataParallelStep):
         main = torch.cuda.current_stream()
         side = PGCTCLossFn._lattice_streams.get(main.cuda_stream)
         if side is None:
-            side = torch.cuda.Stream()
+            from . import streams
+            side = streams.side_stream("loss_section")
             PGCTCLossFn._lattice_streams[main.cuda_stream] = side
         return side
 
