@@ -345,6 +345,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=("headline", "bucketed"), default="headline")
+    ap.add_argument("--event-every", type=int, default=4, help="HIP-event timing of the sweeps and phases on every n-th timed step")
     ap.add_argument("--h2d", choices=("prefetch", "serial", "dma_prefetch", "dma_serial", "resident"), default="prefetch",
                     help="how each step's batch reaches HBM inside the timed region (resident: not at all, diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -448,10 +449,19 @@ def main():
         if rank == 0:
             print(f"[bench] warmup step {i} done", file=sys.stderr, flush=True)
     barrier()
-    hipops.profile_reset(True, only=("lstm_",))     # live HIP-event timing of the dominant kernels (6 launches a step)
+    # live HIP-event timing of the dominant kernels (6 launches a step) and of the step's phases -- on every
+    # --event-every-th step of the timed region: an event record costs the stream it is issued on ~5 us
+    # (tools/dev/tools_marker_cost.py), 14 of them per instrumented step
+    hipops.profile_reset(True, only=("lstm_",))
+    every = max(1, args.event_every)
+    n_sampled = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one_step(mark=True)
+    for i in range(args.steps):
+        sampled = (i + 1) % every == 0 or (args.steps < every and i == args.steps - 1)   # never the step right behind the barrier: its front end is host-bound
+        hipops.profile_pause(not sampled)
+        n_sampled += int(sampled)
+        loss = one_step(mark=sampled)
+    hipops.profile_pause(False)
     host_enqueue_s = time.perf_counter() - t0       # how long the host needed to ENQUEUE the steps (it runs ahead of the GPU)
     barrier()
     dt_local = time.perf_counter() - t0
@@ -463,7 +473,7 @@ def main():
     hipops.profile_reset(True)
     for _ in range(2):
         one_step()
-    extra = {k: (v[0] * args.steps / 2.0, v[1] * args.steps / 2.0) for k, v in hipops.profile_collect().items() if k not in prof}
+    extra = {k: (v[0] * n_sampled / 2.0, v[1] * n_sampled / 2.0) for k, v in hipops.profile_collect().items() if k not in prof}
     prof.update(extra)
     hipops.profile_reset(False)
     hipops.lstm_assert_no_timeouts()      # every rank: a timed-out sweep would make the number meaningless
@@ -535,7 +545,8 @@ def main():
             "roofline_step": {"algorithmic_tflops": step_tf, "gflop_per_step_per_gpu": gflop_step_gpu,
                               "frac_vs_bf16x3_peak_833": step_tf / peak, "frac_vs_fp32_mfma_peak_157.3": step_tf / FP32_MFMA_PEAK_TF,
                               "note": "whole-step dense contraction flops (SURVEY §8d: 28.65 GFLOP per 1000-frame utterance) per GPU / ms_per_step"},
-            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "kernel_ms_per_step": {k: v[0] / max(n_sampled, 1) for k, v in prof.items()},
+            "event_timed_steps": n_sampled,
             "host_enqueue_ms_per_step": host_enqueue_s / args.steps * 1e3,
             "phase_ms_per_step": phases,
             "loss": float(loss.item()),

@@ -54,6 +54,16 @@ class grad_overlap:
             cls._sides2[k] = streams.side_stream("feed")
         return cls._sides2[k]
 
+    _recent = {}       # the last event recorded on the main stream in the running backward pass (per main stream)
+
+    @classmethod
+    def note_event(cls, ev):
+        cls._recent[cls._key()] = ev
+
+    @classmethod
+    def take_event(cls):
+        return cls._recent.pop(cls._key(), None)
+
     @classmethod
     def pending(cls):
         return cls._pendings.setdefault(cls._key(), [])
@@ -96,6 +106,7 @@ class grad_overlap:
             cls._deferred.clear()
             raise RuntimeError("a deferred input gradient was never consumed by a BLSTM layer (grad_overlap/FEED_AHEAD)")
         cls.flush()
+        cls._recent.pop(cls._key(), None)
         if cls._key() in cls._sides:
             torch.cuda.current_stream().wait_stream(cls.side_stream())
 
@@ -206,6 +217,7 @@ class LinearFn(torch.autograd.Function):
             # only dx is on the chain: the weight gradient joins the side-stream work that runs beside the next sweep
             done = torch.cuda.Event()
             done.record()
+            grad_overlap.note_event(done)
 
             def weight_grads():
                 hipops.gemm(dy2, x2, wg, M=N, N=K, K=rows, transA=True, lda=N, splitk=_pick_splitk(N, K, rows), accumulate=True)
@@ -309,8 +321,13 @@ class BLSTMLayerFn(torch.autograd.Function):
             else:
                 dout = hipops.dropout(dout, *ctx.out_dropout)
         if grad_overlap.enabled:
-            before = torch.cuda.Event()
-            before.record()
+            # "the main stream is about to launch the sweep": the last event recorded on it in this backward pass (the head's
+            # `done`, the `swept` of the layer above) is late enough -- the side stream's gate kernel waits for the sweep's
+            # clusters anyway -- and every event record costs the stream ~5 us (tools/dev/tools_marker_cost.py)
+            before = grad_overlap.take_event()
+            if before is None:
+                before = torch.cuda.Event()
+                before.record()
         if rec is not None:
             # dout does not exist yet: the layer above left its input-gradient GEMM (and the dropout between the layers)
             # to us.  The sweep goes first; the GEMM follows on the side stream and feeds it row tile by row tile.
@@ -328,6 +345,7 @@ class BLSTMLayerFn(torch.autograd.Function):
                 streams.hold(dout, grad_overlap.side_stream())
             swept = torch.cuda.Event()
             swept.record()
+            grad_overlap.note_event(swept)
             if not ctx.sweep_follows and grad_overlap.upper_grads_hook is not None:
                 # first layer: the head's and the upper layers' weight gradients are all on the side stream now
                 # (N > 1: the trainer starts their all-reduce there, behind this sweep and under the tail GEMMs)

@@ -45,6 +45,13 @@ def profile_reset(enable, only=None):
     _prof_events.clear()
 
 
+def profile_pause(paused):
+    """Stop / resume recording without dropping what was collected (bench.py instruments every n-th step: each event
+    record costs the stream ~5 us)."""
+    global _prof_on
+    _prof_on = not paused
+
+
 def profile_collect():
     """name -> (total ms, launches); synchronises."""
     torch.cuda.synchronize()
