@@ -9,7 +9,7 @@ started 420 us late).  Which HIP stream lands on the hardware queue that is coup
 main stream's depends on the order in which streams were created in the process (ROCclr deals streams onto GPU_MAX_HW_QUEUES
 queues round-robin), so it is MEASURED: candidates are created, each is blocked in turn behind a short chain of tiny kernels on
 the serving stream, and the ones that stretch the chain are never handed out (they stay allocated, so that later streams do not
-take their place in the deal).  The probe runs once per (device, serving stream), synchronises, and takes ~20 ms.
+take their place in the deal).  The probe runs once per (device, serving stream), synchronises, and takes ~30 ms.
 """
 import os
 
@@ -18,16 +18,16 @@ import torch
 from . import hipops
 
 VET = os.environ.get("PGASR_VET_STREAMS", "1") != "0"     # 0: hand out streams in creation order (A/B switch)
-_CANDIDATES = 10          # more than one full deal of the 7 non-default hardware queues
+_CANDIDATES = 32          # torch.cuda.Stream() draws round-robin from a pool of 32 HIP streams per device: one full turn
 _CHAIN = 8                # tiny kernels on the serving stream per measurement
 _state = {}               # (device index, serving stream handle) -> {"good": [...], "named": {...}, "report": [...]}
 
 
-def _chain_us(main, blocked, tiny, zero_words):
+def _chain_us(main, blocked, tiny, zero_words, reps=1):
     """Time of _CHAIN dependent tiny kernels on ``main`` (current stream) that start behind a 300-us sleeper -- so that the host
     has enqueued everything, the blocked stream's wait included, before the first of them is dispatched."""
     best = None
-    for _ in range(3):
+    for _ in range(reps):
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
@@ -49,6 +49,9 @@ def _chain_us(main, blocked, tiny, zero_words):
 
 
 def _vet(main):
+    """One full turn of torch's stream pool is taken and measured, so that (a) the streams handed out are known not to be
+    coupled to ``main`` and (b) the NEXT stream anybody creates (the process group's collective stream, for one) is pool
+    stream 0 again, whose verdict is known: if it is a coupled one, the turn is advanced past it."""
     dev = torch.device("cuda", torch.cuda.current_device())
     tiny = torch.zeros(1, device=dev)
     zero_words = torch.zeros(8, dtype=torch.int32, device=dev)
@@ -56,24 +59,37 @@ def _vet(main):
     for s in cands:                      # a stream's hardware queue exists from its first use
         with torch.cuda.stream(s):
             tiny.add_(1)
-    base = _chain_us(main, None, tiny, zero_words)
+    base = _chain_us(main, None, tiny, zero_words, reps=3)
     times = [_chain_us(main, s, tiny, zero_words) for s in cands]
     typical = sorted(times)[len(times) // 2]
-    good, report = [], [("nothing blocked", base, "")]
+    for i, s in enumerate(cands):        # a slow reading is confirmed before it condemns a stream
+        if times[i] >= 1.5 * typical:
+            times[i] = min(times[i], _chain_us(main, s, tiny, zero_words, reps=2))
+    good, report, verdicts = [], [("nothing blocked", base, "")], []
     for i, (s, us) in enumerate(zip(cands, times)):
         # measured with 8 tiny kernels: nothing blocked 17 us, an ordinary stream blocked 28 us, the coupled one 53 us (with
         # 250-workgroup kernels on the serving stream the same stream costs +75 us PER KERNEL)
-        ok = us < 1.5 * typical
-        report.append((f"candidate {i} blocked", us, "ok" if ok else "coupled to the serving stream's queue: never handed out"))
+        # ... and 17 us again for a stream that shares the serving stream's OWN hardware queue: its wait costs nothing, but
+        # nothing on it can ever run beside the serving stream
+        coupled, same_queue = us >= 1.5 * typical, us < 0.5 * (base + typical)
+        ok = not coupled and not same_queue
+        verdicts.append(ok)
+        report.append((f"pool stream {i} blocked", us, "ok" if ok else ("coupled to the serving stream's queue: never handed out" if coupled
+                                                                       else "shares the serving stream's hardware queue: never handed out")))
         if ok:
             good.append(s)
+    burnt = []
+    for ok in verdicts:                  # the pool's next stream is candidate 0 again, then 1, ...
+        if ok:
+            break
+        burnt.append(torch.cuda.Stream())
     if len(good) < 4:                    # never seen; do not fail a training run over a scheduling heuristic
-        good = cands
+        good = list(cands)
     if os.environ.get("PGASR_DEBUG"):
         import sys
         for r in report:
             print("[pgasr streams]", *r, file=sys.stderr)
-    return {"good": good, "keep": cands, "named": {}, "report": report}
+    return {"good": good, "keep": cands + burnt, "named": {}, "report": report}
 
 
 def side_stream(name):
