@@ -465,3 +465,42 @@ def test_headline_size_loss_and_gradient_parity():
     assert rel_err(logits.detach().cpu(), logits_ref.detach()) < 1e-3
     greedy, _ = hipops.frame_argmax_sample(logits_ref.detach().contiguous().to(DEV), want_sample=False)
     assert np.array_equal(greedy.cpu().numpy(), np.argmax(logits_ref.detach().numpy(), axis=2))
+
+
+def test_held_tensors_give_the_same_steps_as_record_stream_and_side_streams_are_vetted():
+    """streams.hold (tensors that cross streams stay alive until the next step begins) against tensor.record_stream:
+    five train-mode steps at a shape with fed sweeps must leave bit-identical parameters; the side streams handed out
+    are distinct, stable per name, and none of them was flagged by the probe."""
+    from policy_gradient_asr_amd import streams
+    from policy_gradient_asr_amd.model import Seq2Seq, weights
+    from policy_gradient_asr_amd.train_step import PolicyGradientTrainer
+    B, F, T, V, L = 32, 80, 64, 29, 6
+    x, targets, fmask, tmask = _make(B, F, T, V, L, [T] * B, [L] * B, 3)
+    batch = [v.to(DEV) for v in (x, targets, fmask, tmask)]
+    flats = {}
+    for mode in (True, False):
+        streams.HOLD = mode
+        try:
+            torch.manual_seed(0)
+            m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(DEV).train()
+            tr = PolicyGradientTrainer(m, lr=1e-3, lam=1.0, seed=5)
+            for _ in range(5):
+                tr.step(*batch)
+            torch.cuda.synchronize()
+            hipops_ok = __import__("policy_gradient_asr_amd.hipops", fromlist=["x"])
+            hipops_ok.lstm_assert_no_timeouts()
+            flats[mode] = tr.flat.clone()
+            assert (len(streams._held) > 0) == mode
+        finally:
+            streams.HOLD = True
+    streams.release()
+    assert torch.equal(flats[True], flats[False])
+    names = ("weight_gradients", "feed", "loss_section")
+    got = [streams.side_stream(n) for n in names]
+    assert len({s.cuda_stream for s in got}) == 3
+    assert [streams.side_stream(n).cuda_stream for n in names] == [s.cuda_stream for s in got]
+    bad = [r for r in streams.report() if "never handed out" in r[2]]
+    main = torch.cuda.current_stream()
+    st = streams._state[(torch.cuda.current_device(), main.cuda_stream)]
+    flagged = {id(s) for s, r in zip(st["keep"], [r for r in st["report"][1:]]) if "never handed out" in r[2]}
+    assert not any(id(s) in flagged for s in got), bad
