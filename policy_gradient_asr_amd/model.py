@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from . import functional as Fh
 from . import hipops
+from . import streams
 
 HID = 256
 
@@ -213,6 +214,7 @@ def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset
                 print("Step {}/{}. Loss: {:>4f}".format(step, len(loader), val))
         losses.append(float(acc) / max(len(loader), 1))
         hipops.lstm_assert_no_timeouts()          # .. and before anything of this epoch is written to disk
+        streams.release()                         # the host has synchronised: nothing of the last step needs keeping alive
         np.save(os.path.join(model_path, "train_loss.npy"), np.array(losses))
         print("Epoch:{}/{} Training loss:{:>4f}".format(epoch, num_epochs, losses[-1]))
 
