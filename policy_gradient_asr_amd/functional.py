@@ -9,6 +9,7 @@ from . import streams
 
 HID = hipops.HID
 FEED_AHEAD = os.environ.get("PGASR_FEED_AHEAD", "1") != "0"   # input projections run beside the forward sweeps they feed
+JOIN_FEED = os.environ.get("PGASR_JOIN_FEED", "0") == "1"   # A/B: main stream joins the feed stream after every fed forward sweep
 FEED_BWD = os.environ.get("PGASR_FEED_BWD", "1") != "0"       # .. and the upper layers' input-gradient GEMMs beside the backward sweeps
 LEAKY_SLOPE = 0.01   # F.leaky_relu default, model.py:50
 
@@ -293,7 +294,11 @@ class BLSTMLayerFn(torch.autograd.Function):
                 hipops.gemm_x3w_feed(x, prepacked.planes, gates, T * B, G, I, bias_perm, busy, done)
             for t_ in (x, gates, done, bias_perm) + tuple(prepacked.planes):
                 streams.hold(t_, side)
-            main.wait_stream(side)
+            # no join: the sweep cannot end before every row tile it waited for is complete, so the stream that ran the sweep
+            # is already behind the feed's stores; what is left of the GEMM then (workgroups finding the tile counter
+            # exhausted) touches no operand.  The next fed sweep's GEMM is ordered on the feed stream itself.
+            if JOIN_FEED:
+                main.wait_stream(side)
         else:
             if x3w:
                 hipops.gemm_x3w(x, prepacked.planes, gates, T * B, G, I, bias=bias_perm)
@@ -477,11 +482,14 @@ def prepack_blstm_layers(layer_params, in_dims, rows=0):
             pk = prepack_blstm(params, in_dim)
             if counters is not None:
                 pk.fed_fwd, pk.fed_bwd = counters[2 * li], counters[2 * li + 1]
-            pk.ready = torch.cuda.Event()
-            pk.ready.record()
             for t in (pk.wih_perm, pk.bias_perm, pk.pack_f, pk.pack_b) + (pk.planes or ()) + (pk.planes_t or ()):
                 streams.hold(t, main)
             out.append(pk)
+        # ONE event for all layers (the packs take ~0.1 ms, the front end that runs meanwhile longer): a cross-stream wait
+        # costs the waiting stream ~10 us even when it is long satisfied (tools/dev/tools_marker_cost.py)
+        ready = torch.cuda.Event()
+        ready.record()
+        out[0].ready = ready
     return out
 
 

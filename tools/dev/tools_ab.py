@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(dev); m.train()
 tr = PolicyGradientTrainer(m, seed=1)
-batch = synth_batch(dev, 1)
+batch = [v.to(dev) for v in synth_batch(1)]
 for rnd in range(3):
     for val in (False, True):
         setattr(grad_overlap, name, val)

@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(dev); m.train()
 tr = PolicyGradientTrainer(m, seed=1)
-batch = synth_batch(dev, 1)
+batch = [v.to(dev) for v in synth_batch(1)]
 marks = []
 orig_f, orig_b = hipops.lstm_layer_fwd, hipops.lstm_layer_bwd
 def fwd(*a, **k):

@@ -30,8 +30,14 @@ def rec_timing(): torch.cuda.Event(enable_timing=True).record()
 def wait_done(): torch.cuda.current_stream().wait_event(old)
 def side_waits_main(): side.wait_stream(torch.cuda.current_stream())
 def rec2(): rec(); rec()
+def wait_other():
+    # a REAL barrier packet: the event is recorded on the other stream now (the host is ahead: it is not complete yet when
+    # the wait is enqueued) but long complete when the main stream gets there
+    with torch.cuda.stream(side):
+        ev = torch.cuda.Event(); ev.record()
+    torch.cuda.current_stream().wait_event(ev)
 base = run(nothing)
 print(f"tiny kernel alone: {base:.2f} us per iteration")
 for name, fn in (("+ event record", rec), ("+ 2 event records", rec2), ("+ timing event record", rec_timing), ("+ wait on a completed event", wait_done),
-                 ("+ side.wait_stream(main)", side_waits_main)):
+                 ("+ side.wait_stream(main)", side_waits_main), ("+ wait on another stream's (earlier) event", wait_other)):
     print(f"{name:32s}: +{run(fn) - base:.2f} us", flush=True)

@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(dev); m.train()
 tr = PolicyGradientTrainer(m, seed=1)
-batch = synth_batch(dev, 1)
+batch = [v.to(dev) for v in synth_batch(1)]
 hi = torch.cuda.Stream(priority=-1)
 def run(stream, n):
     if stream is None:

@@ -15,7 +15,7 @@ for mode in ("eval", "train"):
     m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(dev)
     m = m.eval() if mode == "eval" else m.train()
     tr = PolicyGradientTrainer(m, lr=0.0, lam=0.0, seed=1)
-    batch = synth_batch(dev, 1)
+    batch = [v.to(dev) for v in synth_batch(1)]
     ref, bad = None, 0
     for i in range(n):
         if mode == "train":

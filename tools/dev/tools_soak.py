@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(dev); m.train()
 tr = PolicyGradientTrainer(m, seed=1)
-batch = synth_batch(dev, 1)
+batch = [v.to(dev) for v in synth_batch(1)]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 t0 = time.perf_counter()
 losses = []
@@ -23,4 +23,5 @@ for key, ws in hipops._ws_cache.items():
     if key[0].startswith("lstm"):
         bad += int(ws[:4].view(torch.int32).item() != 0)
 ls = torch.stack(losses).float().cpu()
-print(f"{n} steps in {dt:.2f} s = {dt / n * 1e3:.2f} ms/step; lstm error words set: {bad}; losses finite: {bool(torch.isfinite(ls).all())}; first/last loss {float(ls[0]):.3f} / {float(ls[-1]):.3f}")
+print(f"peak device memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB; "
+      f"{n} steps in {dt:.2f} s = {dt / n * 1e3:.2f} ms/step; lstm error words set: {bad}; losses finite: {bool(torch.isfinite(ls).all())}; first/last loss {float(ls[0]):.3f} / {float(ls[-1]):.3f}")

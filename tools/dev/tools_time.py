@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(dev); m.train(os.environ.get("PGASR_TT_TRAIN","0")=="1")
 tr = PolicyGradientTrainer(m, seed=1)
-batch = synth_batch(dev, 1)
+batch = [v.to(dev) for v in synth_batch(1)]
 for i in range(2):
     t0 = time.perf_counter(); tr.step(*batch); torch.cuda.synchronize()
     print(f"step {i}: {(time.perf_counter()-t0)*1e3:.1f} ms", flush=True)
