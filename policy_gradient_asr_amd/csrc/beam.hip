@@ -456,6 +456,9 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
         // no wait on the K-round chain)
 
         // ---- K rounds: pop the winners in rank order ----
+        // (Measured and not kept: TWO winners per round from one all-reduce over (first, second) pairs of high words -- exact,
+        // all tests green, but the pair combine is 6 VALU operations per DPP step against one fused v_max_u32_dpp, and
+        // 8 readlanes against 4: 5.28 against 4.89 us per frame at beam 16, 2.82 against 2.68 at beam 5.)
         unsigned packed = 0u;
         int nnew = 0;
         for (int r = 0; r < K; ++r) {
