@@ -77,19 +77,19 @@ def _vet(main):
         report.append((f"pool stream {i} blocked", us, "ok" if ok else ("coupled to the serving stream's queue: never handed out" if coupled
                                                                        else "shares the serving stream's hardware queue: never handed out")))
         if ok:
-            good.append(s)
+            good.append((i, s))
     burnt = []
     for ok in verdicts:                  # the pool's next stream is candidate 0 again, then 1, ...
         if ok:
             break
         burnt.append(torch.cuda.Stream())
     if len(good) < 4:                    # never seen; do not fail a training run over a scheduling heuristic
-        good = list(cands)
+        good = list(enumerate(cands))
     if os.environ.get("PGASR_DEBUG"):
         import sys
         for r in report:
             print("[pgasr streams]", *r, file=sys.stderr)
-    return {"good": good, "keep": cands + burnt, "named": {}, "report": report}
+    return {"good": good, "keep": cands + burnt, "named": {}, "report": report, "taken": []}
 
 
 def side_stream(name):
@@ -101,12 +101,16 @@ def side_stream(name):
         if VET:
             st = _vet(main)
         else:
-            st = {"good": None, "keep": [], "named": {}, "report": []}
+            st = {"good": None, "keep": [], "named": {}, "report": [], "taken": []}
         _state[key] = st
     s = st["named"].get(name)
     if s is None:
         if st["good"]:
-            s = st["good"].pop(0)
+            # the coupling is pairwise and periodic (tools/dev/tools_blocked_queues.py with SERVE=i: pool stream i is slowed by
+            # stream i + 4 of the 8 hardware queues, whichever of the two serves): two streams of one step never sit 4 apart
+            pick = next((k for k, (i, _) in enumerate(st["good"]) if all((i - t) % 8 != 4 for t in st["taken"])), 0)
+            i, s = st["good"].pop(pick)
+            st["taken"].append(i)
         else:
             s = torch.cuda.Stream()
         st["named"][name] = s

@@ -24,22 +24,26 @@ pool = [torch.cuda.Stream() for _ in range(NPOOL)]
 for sd in pool:                      # make every stream real (its hardware queue is created on first use)
     with torch.cuda.stream(sd): tiny.add_(1)
 torch.cuda.synchronize()
+SERVE = int(os.environ.get("SERVE", "-1"))      # -1: the chain runs on the default stream, else on pool[SERVE]
 def measure(blocked):
     res = []
+    serving = torch.cuda.current_stream() if SERVE < 0 else pool[SERVE]
     for rep in range(7):
         torch.cuda.synchronize()
-        ea = torch.cuda.Event(enable_timing=True); eb = torch.cuda.Event(enable_timing=True)
-        long_kernel()                      # ~1 ms during which the host enqueues everything below
-        ea.record(); chain(); eb.record()
-        later = torch.cuda.Event(); later.record()
+        with torch.cuda.stream(serving):
+            ea = torch.cuda.Event(enable_timing=True); eb = torch.cuda.Event(enable_timing=True)
+            long_kernel()                      # ~1 ms during which the host enqueues everything below
+            ea.record(); chain(); eb.record()
+            later = torch.cuda.Event(); later.record()
         for i in blocked:
+            if i == SERVE: continue
             pool[i].wait_event(later)
             with torch.cuda.stream(pool[i]): tiny.add_(1)
         torch.cuda.synchronize()
         res.append(ea.elapsed_time(eb) * 1e3)
     res.sort()
     return res[3], res[0], res[-1]
-print("predecessor:", os.environ.get("PRED", "gemms"))
+print("predecessor:", os.environ.get("PRED", "gemms"), " serving stream:", "default" if SERVE < 0 else f"pool[{SERVE}]")
 print(f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}; pool of {NPOOL} streams; 6 dependent 35-us kernels on the default stream")
 print("nothing blocked: %.1f us (min %.1f max %.1f)" % measure([]))
 for i in range(NPOOL):
