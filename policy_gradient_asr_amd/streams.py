@@ -29,15 +29,16 @@ def _chain_us(main, blocked, tiny, zero_words, reps=1):
     best = None
     for _ in range(reps):
         torch.cuda.synchronize()
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        hipops.stream_gate(zero_words.data_ptr(), timeout_us=300)
-        e0.record()
-        for _k in range(_CHAIN):
-            tiny.add_(1)
-        e1.record()
-        later = torch.cuda.Event()
-        later.record()
+        with torch.cuda.stream(main):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            hipops.stream_gate(zero_words.data_ptr(), timeout_us=300)
+            e0.record()
+            for _k in range(_CHAIN):
+                tiny.add_(1)
+            e1.record()
+            later = torch.cuda.Event()
+            later.record()
         if blocked is not None:
             blocked.wait_event(later)
             with torch.cuda.stream(blocked):
@@ -89,7 +90,8 @@ def _vet(main):
         import sys
         for r in report:
             print("[pgasr streams]", *r, file=sys.stderr)
-    return {"good": good, "keep": cands + burnt, "named": {}, "report": report, "taken": []}
+    return {"good": good, "keep": cands + burnt, "named": {}, "report": report, "taken": [], "typical": typical,
+            "probe": (tiny, zero_words)}
 
 
 def side_stream(name):
@@ -108,8 +110,17 @@ def side_stream(name):
         if st["good"]:
             # the coupling is pairwise and periodic (tools/dev/tools_blocked_queues.py with SERVE=i: pool stream i is slowed by
             # stream i + 4 of the 8 hardware queues, whichever of the two serves): two streams of one step never sit 4 apart
-            pick = next((k for k, (i, _) in enumerate(st["good"]) if all((i - t) % 8 != 4 for t in st["taken"])), 0)
-            i, s = st["good"].pop(pick)
+            # ... the index rule is a first guess; what counts is measured: the newcomer must not stretch a chain served by a
+            # stream already handed out, nor the other way round
+            while True:
+                pick = next((k for k, (i, _) in enumerate(st["good"]) if all((i - t) % 8 != 4 for t in st["taken"])), 0)
+                i, s = st["good"].pop(pick)
+                tiny, zero_words = st["probe"]
+                clash = any(_chain_us(a, b, tiny, zero_words) >= 1.5 * st["typical"]
+                            for o in st["named"].values() for a, b in ((o, s), (s, o)))
+                if not clash or not st["good"]:
+                    break
+                st["report"].append((f"pool stream {i}", 0.0, "coupled to another side stream of the step: not handed out"))
             st["taken"].append(i)
         else:
             s = torch.cuda.Stream()
