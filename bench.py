@@ -379,6 +379,10 @@ def main():
     # are really issued, buckets, stream and event waits included -- what a collective stream does to the step's own streams
     # can be seen without a second GPU
     solo_collective = world == 1 and os.environ.get("PGASR_BENCH_SOLO_COLLECTIVE", "") == "1"
+    if world > 1 or solo_collective:
+        # before the communicator takes its stream from torch's pool: see streams.prime()
+        from policy_gradient_asr_amd import streams
+        streams.prime()
     if world > 1:
         if rehearse:
             dist.init_process_group("gloo")

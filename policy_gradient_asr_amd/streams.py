@@ -94,6 +94,14 @@ def _vet(main):
             "probe": (tiny, zero_words)}
 
 
+def prime():
+    """Run the probe for the CURRENT stream now.  Call it before ``dist.init_process_group("nccl", device_id=...)``: the
+    process group takes ITS stream from the same pool when the communicator is created, and a collective stream is blocked
+    on event waits for most of a step -- it should be one of the streams this module has looked at, not the one that happens
+    to be coupled to the stream the step runs on."""
+    side_stream("weight_gradients")
+
+
 def side_stream(name):
     """The side stream called ``name`` of the CURRENT stream (one per name and serving stream; created and vetted on first use)."""
     main = torch.cuda.current_stream()
