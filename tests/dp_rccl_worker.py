@@ -43,6 +43,8 @@ def main():
     rank, world, port, out_dir, lam = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], float(sys.argv[5])
     dev = torch.device("cuda", rank)
     torch.cuda.set_device(dev)
+    from policy_gradient_asr_amd import streams
+    streams.prime()          # before the communicator takes its stream from torch's pool
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev)
     try:
         from policy_gradient_asr_amd.train_step import shard_slice
