@@ -49,13 +49,37 @@ def _free_port():
     return p
 
 
+def visible_gpu_count():
+    """GPUs this process may use, WITHOUT any HIP / ROCr / amdsmi call: the KFD topology in sysfs (a GPU node has
+    simd_count > 0, a CPU node 0), cut down by the *_VISIBLE_DEVICES lists.  None when sysfs does not say (the children
+    then validate their own device index).  The parent of a multi-rank run must never initialise the GPU: a process that
+    has may not start children that exec."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as fi:
+                for line in fi:
+                    k, _, v = line.partition(" ")
+                    if k == "simd_count":
+                        n += int(v) > 0
+                        break
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        lst = os.environ.get(var)
+        if lst is not None:
+            n = min(n, len([x for x in lst.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(n):
     """Parent of a `--gpus n` run without torchrun: start n children (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set), pass
-    their output through, exit with the first non-zero code.  No HIP call is made here (device_count() does not
-    initialise the GPU on this image), and nothing is exec'ed from a process that has."""
+    their output through, exit with the first non-zero code.  No HIP call is made here -- the GPU count comes from
+    sysfs (visible_gpu_count) -- and nothing is exec'ed from a process that has initialised the GPU."""
     rehearse = os.environ.get("PGASR_BENCH_REHEARSE", "") == "1"
-    ndev = torch.cuda.device_count()
-    if ndev < n and not rehearse:
+    ndev = visible_gpu_count()
+    if ndev is not None and ndev < n and not rehearse:
         print(f"[bench] --gpus {n} but only {ndev} GPU(s) are visible", file=sys.stderr)
         return 2
     port = _free_port()
@@ -273,7 +297,10 @@ def cpu_baseline(steps=3):
                             "CPU backward is O(T^2): at T=1000 the survey measured 121 s/step on 8 cores (0.26 utt/s)"}}}
 
 
-def parity_vs_fp64(model, trainer, batch):
+_fp64_ref = {}
+
+
+def parity_vs_fp64(model, trainer, batch, brief=False):
     """One UNTIMED eval-mode CTC step (lambda = 0, no sampling) of the benchmarked model on the GPU against the oracle in
     fp64 on the same weights and inputs: relative error of the loss and max-norm relative error over all parameter
     gradients.  Travels with the throughput number as its precision statement."""
@@ -290,17 +317,21 @@ def parity_vs_fp64(model, trainer, batch):
     torch.cuda.synchronize()
     g_gpu = {k: v.grad.detach().double().cpu() for k, v in model.named_parameters()}
     model.train(was_training)
-    torch.set_num_threads(_cpu_cores())
-    p = {(k[len("encoder."):] if k.startswith("encoder.") else k): v.detach().double().cpu().requires_grad_(True)
-         for k, v in model.named_parameters()}
-    t0 = time.perf_counter()
-    xc, fm = x.double().cpu(), fmask.cpu()
-    lens = fm.sum(1).long()
-    enc = model_ref.encoder_forward_torch(p, xc, fm, packed=bool((lens != xc.shape[2]).any()))
-    lp = torch.log_softmax(model_ref.head_logits_torch(p, enc), 2)
-    ref = torch.nn.functional.ctc_loss(lp, targets.cpu().long(), lens, tg_len.cpu().long(), blank=0, reduction="mean")
-    ref.backward()
-    print(f"[bench] fp64 parity step on the CPU: {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+    key = (trainer.nstep, x.data_ptr())       # the two precision variants are checked on the SAME weights: one fp64 CPU step serves both
+    if _fp64_ref.get("key") != key:
+        torch.set_num_threads(_cpu_cores())
+        p = {(k[len("encoder."):] if k.startswith("encoder.") else k): v.detach().double().cpu().requires_grad_(True)
+             for k, v in model.named_parameters()}
+        t0 = time.perf_counter()
+        xc, fm = x.double().cpu(), fmask.cpu()
+        lens = fm.sum(1).long()
+        enc = model_ref.encoder_forward_torch(p, xc, fm, packed=bool((lens != xc.shape[2]).any()))
+        lp = torch.log_softmax(model_ref.head_logits_torch(p, enc), 2)
+        ref = torch.nn.functional.ctc_loss(lp, targets.cpu().long(), lens, tg_len.cpu().long(), blank=0, reduction="mean")
+        ref.backward()
+        print(f"[bench] fp64 parity step on the CPU: {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+        _fp64_ref.update(key=key, p=p, ref=ref)
+    p, ref = _fp64_ref["p"], _fp64_ref["ref"]
     worst, worst_l2, worst_name = 0.0, 0.0, ""
     for k, v in g_gpu.items():
         rk = k[len("encoder."):] if k.startswith("encoder.") else k
@@ -309,14 +340,32 @@ def parity_vs_fp64(model, trainer, batch):
         worst_l2 = max(worst_l2, float((v - r).norm() / (r.norm() + 1e-300)))
         if e > worst:
             worst, worst_name = e, rk
-    return {"loss": abs(float(loss.detach()) - float(ref.detach())) / abs(float(ref.detach())), "param_grads_maxnorm": worst,
-            "param_grads_maxnorm_tensor": worst_name, "param_grads_frobenius": worst_l2,
+    res = {"loss": abs(float(loss.detach()) - float(ref.detach())) / abs(float(ref.detach())), "param_grads_maxnorm": worst,
+           "param_grads_maxnorm_tensor": worst_name, "param_grads_frobenius": worst_l2}
+    if brief:
+        return res
+    return {**res,
             "what": "eval-mode CTC step (lambda=0) of the benchmarked model (after the timed steps) vs torch-CPU fp64 on the same "
                     "weights and batch; worst tensor.  The input layer's two tensors sit behind leaky_relu': a pre-activation "
                     "that is zero to rounding changes side between two fp32 evaluations and moves one summand by 100x"}
 
 
 # ------------------------------------------------------------------------------------------------
+def sweep_roofline(prof, n_sampled, frames_per_step):
+    """The dominant kernel's roofline figures from the HIP-event record of the SAMPLED steps: prof maps kernel name ->
+    (total ms, launches) over n_sampled instrumented steps.  Algorithmic flops of one sweep launch: h (B,256) x W_hh^T
+    (256,1024), two directions, one multiply-add per frame of the chain."""
+    sweeps = {k: v for k, v in prof.items() if k.startswith("lstm_")}
+    name, (tot_ms, calls) = max(sweeps.items(), key=lambda kv: kv[1][0]) if sweeps else ("none", (0.0, 1))
+    tavg = frames_per_step / B_PER_GPU                                # average steps of a sweep's chain
+    flops_per_launch = 2.0 * 2 * B_PER_GPU * 256 * 1024 * tavg
+    avg_ms = tot_ms / max(calls, 1)
+    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    return {"kernel": name, "avg_launch_ms": avg_ms, "achieved": achieved,
+            "peak": BF16_DENSE_PEAK_TF / 3.0,          # 3 bf16 MFMA products per algorithmic fp32 flop
+            "flops_per_launch": flops_per_launch, "launches_per_step": calls / max(n_sampled, 1)}
+
+
 def allreduce_probe(trainer, dev, reps=10):
     """Wall time of the step's two gradient buckets as stand-alone RCCL all-reduces (barrier-bracketed, outside the
     timed region): what the early bucket hides under the tail of backward and what the late one adds."""
@@ -348,6 +397,8 @@ def main():
     ap.add_argument("--event-every", type=int, default=4, help="HIP-event timing of the sweeps and phases on every n-th timed step")
     ap.add_argument("--h2d", choices=("prefetch", "serial", "dma_prefetch", "dma_serial", "resident"), default="prefetch",
                     help="how each step's batch reaches HBM inside the timed region (resident: not at all, diagnostic)")
+    ap.add_argument("--long-steps", type=int, default=200, help="second, longer timed region after the headline one (0 = off)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the configs[4] and f32-precision legs that follow the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -373,6 +424,9 @@ def main():
     rehearse = os.environ.get("PGASR_BENCH_REHEARSE", "") == "1"
     if rehearse:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():      # a rank validates its own device (the parent does not touch the GPU)
+        print(f"[bench] rank {rank} wants device {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
+        sys.exit(2)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     # plumbing rehearsal for a one-GPU box (never used by the driver): a 1-rank RCCL group whose all-reduces (identities)
@@ -481,6 +535,60 @@ def main():
     prof.update(extra)
     hipops.profile_reset(False)
     hipops.lstm_assert_no_timeouts()      # every rank: a timed-out sweep would make the number meaningless
+
+    def timed_leg(fd, steps, warm):
+        """ms per step (max over ranks) of `steps` steps fed by `fd`, barrier-bracketed like the headline region."""
+        for _ in range(warm):
+            trainer.step(*fd.next()); fd.done()
+        barrier()
+        t_0 = time.perf_counter()
+        for _ in range(steps):
+            trainer.step(*fd.next()); fd.done()
+        barrier()
+        sec = time.perf_counter() - t_0
+        if world > 1:
+            tmax = torch.tensor([sec], device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            sec = float(tmax.item())
+        hipops.lstm_assert_no_timeouts()
+        return sec / steps * 1e3
+
+    # ---- legs that follow the headline region (all outside it; every rank runs them: they contain collectives) ----
+    long_run = None
+    if args.long_steps > 0:
+        lms = timed_leg(feeder, args.long_steps, 0)
+        long_run = {"steps": args.long_steps, "ms_per_step": lms, "value": B_PER_GPU * world / (lms * 1e-3),
+                    "note": "same workload and feeder as the headline region, timed again over a longer run"}
+    bucketed_leg = None
+    if not bucketed and not args.no_extra_legs:
+        # configs[4] in the same driver-run line: the reference's reward hypothesis (prefix beam search, beam 16) on
+        # length-bucketed batches U[T/2,T], measured after the headline with the same model and trainer
+        pool = bucketed_pool(rank, world, n_batches=8, seed=0)
+        bhost = [synth_batch(1000 + 17 * i + rank, lens, pin=True) for i, lens in enumerate(pool)]
+        trainer.reward_decoder, trainer.beam_size = "beam", 16
+        bms = timed_leg(BatchFeeder(bhost, dev, args.h2d, trainer), 40, 8)
+        trainer.reward_decoder = "greedy"
+        bframes = sum(sum(lens) for lens in pool) / len(pool)
+        bucketed_leg = {"ms_per_step": bms, "utt_per_s": B_PER_GPU * world / (bms * 1e-3), "steps": 40, "warmup": 8,
+                        "frames_per_step_per_gpu": bframes,
+                        "workload": "configs[4]: beam-16 prefix-search reward hypothesis + collapse_fn + edit distance, lengths "
+                                    "U[500,1000] in length-bucketed batches balanced by frames, B=32/GPU, train mode, Adam, H2D inside"}
+    precision_variants, parity_batch = None, None
+    if world == 1 and not bucketed and not args.no_extra_legs:
+        # what the reference's own arithmetic (torch fp32) costs on this chip: the same step in precision mode "f32"
+        # (exact fp32 MFMA GEMMs, 3-plane / 6-product sweeps, no feed-ahead), outside the headline region
+        precision_variants = {"bf16x3": {"ms_per_step": (long_run or {}).get("ms_per_step", dt_local / args.steps * 1e3),
+                                         "utt_per_s": B_PER_GPU / ((long_run or {}).get("ms_per_step", dt_local / args.steps * 1e3) * 1e-3)}}
+        trainer.precision = "f32"
+        fms = timed_leg(BatchFeeder(host, dev, args.h2d, trainer), 40, 5)
+        precision_variants["f32"] = {"ms_per_step": fms, "utt_per_s": B_PER_GPU / (fms * 1e-3), "steps": 40, "warmup": 5,
+                                     "arithmetic": "every hoisted GEMM on the exact fp32 MFMA (v_mfma_f32_32x32x2_f32); recurrent sweeps on "
+                                                   "3 bf16 planes x 6 products (all terms >= 2^-24); projections before their sweeps"}
+        if not args.no_parity:
+            parity_batch = [t.to(dev) for t in host[0]]
+            with hipops.precision("f32"):
+                precision_variants["f32"]["max_rel_err_vs_fp64"] = parity_vs_fp64(model, trainer, parity_batch, brief=True)
+        trainer.precision = None
     dt = dt_local
     per_rank_ms = [dt_local / args.steps * 1e3]
     ar = None
@@ -497,14 +605,8 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = B_PER_GPU * world * args.steps / dt
-        # dominant kernel: the LSTM sweep with the larger share
-        sweeps = {k: v for k, v in prof.items() if k.startswith("lstm_")}
-        name, (tot_ms, calls) = max(sweeps.items(), key=lambda kv: kv[1][0]) if sweeps else ("none", (0.0, 1))
-        tavg = sum(frames) / len(frames) / B_PER_GPU                  # average steps of a sweep's chain
-        flops_per_launch = 2.0 * 2 * B_PER_GPU * 256 * 1024 * (T if not bucketed else tavg)   # h(B,256) x W_hh^T(256,1024), 2 dirs
-        avg_ms = tot_ms / max(calls, 1)
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        peak = BF16_DENSE_PEAK_TF / 3.0           # 3 bf16 MFMA products per algorithmic fp32 flop
+        rl = sweep_roofline(prof, n_sampled, sum(frames) / len(frames))
+        name, avg_ms, achieved, peak, flops_per_launch = rl["kernel"], rl["avg_launch_ms"], rl["achieved"], rl["peak"], rl["flops_per_launch"]
         traffic, traffic_src = None, None         # HBM bytes per launch of that kernel from the committed PMC passes
         for fname in ("r02_pmc.json", "r01_pmc.json"):     # written by tools/pmc_summary.py
             try:
@@ -539,7 +641,7 @@ def main():
             "ms_per_step_per_rank": per_rank_ms,
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_launch_ms": avg_ms, "launches_per_step": calls / args.steps,
+                         "avg_launch_ms": avg_ms, "launches_per_step": rl["launches_per_step"],
                          "algorithmic_gflop_per_launch": flops_per_launch / 1e9,
                          "peak_note": "algorithmic fp32 flops against the bf16 dense MFMA peak / 3 (the kernel issues 3 bf16 "
                                       "products per flop): identical to issued bf16 flops / 2500 TF",
@@ -557,8 +659,17 @@ def main():
         }
         if ar is not None:
             out["allreduce_ms"] = ar
+        if long_run is not None:
+            out["long_run"] = long_run
+        if bucketed_leg is not None:
+            out["bucketed"] = bucketed_leg
         if world == 1 and not args.no_parity:
-            out["max_rel_err_vs_fp64"] = parity_vs_fp64(model, trainer, [t.to(dev) for t in host[0]])
+            out["max_rel_err_vs_fp64"] = parity_vs_fp64(model, trainer, parity_batch if parity_batch is not None else [t.to(dev) for t in host[0]])
+        if precision_variants is not None:
+            if "max_rel_err_vs_fp64" in out:
+                precision_variants["bf16x3"]["max_rel_err_vs_fp64"] = {k: out["max_rel_err_vs_fp64"][k] for k in
+                                                                         ("loss", "param_grads_maxnorm", "param_grads_maxnorm_tensor", "param_grads_frobenius")}
+            out["precision_variants"] = precision_variants
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

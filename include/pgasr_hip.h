@@ -37,7 +37,7 @@ typedef enum pgasr_status {
     PGASR_ERR_TIMEOUT = 5        /* a bounded in-kernel wait gave up (persistent LSTM) */
 } pgasr_status;
 
-#define PGASR_ABI_VERSION 2
+#define PGASR_ABI_VERSION 3
 
 int pgasr_abi_version(void);
 const char* pgasr_status_string(int status);
@@ -173,7 +173,7 @@ int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
  * pgasr_split_bf16_planes: src (rows x cols fp32, leading dim ld) -> dense planes hi, lo of
  *   (rows x cols) bf16, or (cols x rows) when transpose != 0; x = hi + lo to ~2^-17 relative.
  * pgasr_gemm_x3w_f32 needs K % 32 == 0, N % 128 == 0, lda % 4 == 0 and 16-byte aligned A / planes, else
- *   PGASR_ERR_UNSUPPORTED (use pgasr_gemm_f32).  dact_y (optional) has C's shape and leading dim. */
+ *   PGASR_ERR_UNSUPPORTED (use pgasr_gemm_f32).  N % 256 == 0 takes the 256 x 256 tile (128 x 128 per wave, 4 waves).  dact_y (optional) has C's shape and leading dim. */
 int pgasr_split_bf16_planes(const float* src, int rows, int cols, int ld, int transpose,
                             unsigned short* hi, unsigned short* lo, void* stream);
 int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
@@ -181,20 +181,24 @@ int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, const unsig
                        const float* dact_y, float slope, void* stream);
 /* The same product FEEDING a forward LSTM sweep that is already running (csrc/gemm_dma.hip, FEED kernel): the input
  * projection leaves the step's critical path.  Persistent workgroups on the XCDs the sweep leaves free draw
- * 256 x 128 tiles in the order the sweep consumes rows (rows are (t, b) time-major; N = the two directions' column
+ * 256 x 256 tiles (256 x 128 when N % 512 != 0) in the order the sweep consumes rows (rows are (t, b) time-major; N = the two directions' column
  * halves: row tile i of direction 0 together with row tile last-i of direction 1), store C write-through and count
  * finished tiles in tiles_done[2][ceil(M/256)] (zeroed by the caller BEFORE the sweep is launched; a word is
- * complete at N/256).  xcc_busy = the sweep's busy counters (pgasr_lstm_busy_offset): workgroups on a busy XCD
+ * complete at pgasr_gemm_x3w_feed_col_tiles(N) = the column tiles of one direction half: the consumer's fed_need).  xcc_busy = the sweep's busy counters (pgasr_lstm_busy_offset): workgroups on a busy XCD
  * take no tile, a second unmasked launch picks up any rest.  workspace >= 1024 bytes; with
  * pgasr_gemm_x3w_feed_workspace_bytes() (32 MB) the first 16 tile groups -- the ones the sweep is waiting for -- are
  * computed as four parallel K-quarters and summed in index order by the last arrival (a tile otherwise takes one CU
- * K/32 x 1.7 us).  The x3w products DEFINE their result as ((q0 + q1) + q2) + q3 over K-quarters accumulated from
- * zero whenever K >= 1024 and K % 128 == 0, in pgasr_gemm_x3w_f32 as well, so both orders give the same bits.
+ * K/32 x 1.7 us).  A tile's result is ONE fp32 accumulation chain over K, except those first tiles of a feed with
+ * K >= 1024 and K % 128 == 0, which are ((q0 + q1) + q2) + q3 over K-quarters accumulated from zero.  To get the same
+ * bits from the sequential order of the same product, call THIS function before the (plain) sweep with xcc_busy = NULL:
+ * the decomposition depends on the arguments only, never on which workgroup computes what.  (On the 256 x 128 tile
+ * -- N % 512 != 0 -- every x3w product with such a K, pgasr_gemm_x3w_f32's too, is the quarter sum.)
  * Call order on the host:
  * zero tiles_done -> pgasr_lstm_layer_fwd_fed (stream S) -> pgasr_stream_gate + this call (another stream that
  * waits for the zeroing).  order 0: rows in the order a forward sweep consumes them; 1: a backward sweep's (the
  * product is then the input gradient of the layer above, feeding pgasr_lstm_layer_bwd_fed).  Needs N % 256 == 0 on top of pgasr_gemm_x3w_f32's conditions and M*ldc*4 < 2^31. */
 size_t pgasr_gemm_x3w_feed_workspace_bytes(void);
+int pgasr_gemm_x3w_feed_col_tiles(int N);
 int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
                             const unsigned short* Wlo, float* C, int ldc, const float* bias,
                             const unsigned* xcc_busy, unsigned* tiles_done, int order, void* workspace,
@@ -221,8 +225,11 @@ int pgasr_log_softmax_rows(const float* logits, long long rows, int V, float* lo
  * pgasr_lstm_pack_weights: torch-layout parameters of the two directions (weight_ih (4H,in),
  *   weight_hh (4H,H), bias_ih, bias_hh (4H); gate rows i|f|g|o) ->
  *     wih_perm (2*4H, in) and bias_perm (2*4H) in column order dir*4H + unit*4 + gate
- *     (bias_perm = bias_ih + bias_hh), and the two register-resident bf16 hi/lo W_hh packs
- *     (pgasr_lstm_pack_bytes each) the sweeps load once.
+ *     (bias_perm = bias_ih + bias_hh), and the two register-resident bf16 W_hh packs
+ *     (pgasr_lstm_pack_bytes(which, planes) each) the sweeps load once.  planes = 2: every fp32 weight as bf16 hi + lo
+ *     (products hi*hi + hi*lo + lo*hi: ~16 operand bits, the default); planes = 3: hi + mid + lo for the fp32-faithful
+ *     sweeps (flags bit 1 below; the reference's nn.LSTM is fp32, model.py:39-44): six products, every term down to
+ *     2^-24 of the product.
  * pgasr_lstm_layer_fwd: gates (T,B,2,H,4) holds xproj = X * wih_perm^T + bias_perm on entry and
  *   the activations (i,f,g,o) on exit; out (T,B,2H) = h; cbuf (T,B,2,H) = c.
  * pgasr_lstm_layer_bwd: dout (T,B,2H) -> gates overwritten in place by d(pre-activation gates);
@@ -234,7 +241,8 @@ int pgasr_log_softmax_rows(const float* logits, long long rows, int V, float* lo
  * HBM rows in an L2-resident ring inside the workspace) per (direction, 16-utterance group) that hand
  * h_t / partial dh sums to each other through global memory every step (self-validating words; plain
  * stores when the cluster is verified to share an XCD, write-through stores otherwise).
- * flags bit 0: force the write-through protocol (testing the placement-independent path); bit 2: no helper
+ * flags bit 0: force the write-through protocol (testing the placement-independent path); bit 1: three-plane
+ * (fp32-faithful) arithmetic -- the W_hh pack must have been made with planes = 3; bit 2: no helper
  * workgroups (the loaders read HBM themselves: slower, but two processes can then share one GPU's XCDs).
  * All workgroups of a sweep wait for each other and must be co-resident: with helpers a sweep takes 20 of an XCD's 32
  * CUs per cluster, so run ONE sweep at a time per GPU (other kernels beside it are fine: they finish on their own) or
@@ -242,11 +250,11 @@ int pgasr_log_softmax_rows(const float* logits, long long rows, int V, float* lo
  * Limit: B <= 128.  workspace (pgasr_lstm_workspace_bytes) holds exchange buffers and an
  * error word (offset: pgasr_lstm_error_offset) that is set when a bounded wait times out.
  * ---------------------------------------------------------------------------------------- */
-size_t pgasr_lstm_pack_bytes(int which);
+size_t pgasr_lstm_pack_bytes(int which, int planes);
 int pgasr_lstm_pack_weights(const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f,
                             const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
                             int in_dim, float* wih_perm, float* bias_perm,
-                            void* whh_pack_fwd, void* whh_pack_bwd, void* stream);
+                            void* whh_pack_fwd, void* whh_pack_bwd, int planes, void* stream);
 int pgasr_lstm_unpack_grads(const float* dwih_perm, const float* dbias_perm, const float* dwhh_perm, int in_dim,
                             float* dw_ih_f, float* dw_hh_f, float* db_ih_f, float* db_hh_f,
                             float* dw_ih_r, float* dw_hh_r, float* db_ih_r, float* db_hh_r,
@@ -330,8 +338,12 @@ int pgasr_ctc_beam_search(const void* log_probs, int is_f64, long long stride_t,
  *   dact_y (optional, n elements): the result is also multiplied by (dact_y > 0 ? 1 : slope) -- the backward
  *   of F.leaky_relu (model.py:50) fused into the backward of the dropout that follows it (model.py:51).
  * pgasr_adam_step: torch.optim.Adam update (model.py:207, lr=5e-4) on flat fp32 buffers;
- *   step is the 1-based step count used for bias correction.  guard0 / guard1 (optional, device int32 words, e.g. the
- *   sweep workspaces' error words): the update is skipped -- parameters and moments untouched -- while either is != 0.
+ *   step is the 1-based count of CALLS.  guard0 / guard1 (optional, device int32 words, e.g. the sweep workspaces'
+ *   error words, or -- data parallel -- the word of the gradient buffer that carried every rank's error flag through
+ *   the all-reduce, so that all replicas skip together): the update is skipped -- parameters and moments untouched --
+ *   while either is != 0.  applied (optional, two device int32 words, zeroed once by the owner): the number of updates
+ *   really applied, kept on the device in ping-pong fashion (word (step-1)&1 is read, word step&1 written); the bias
+ *   correction then uses that count + 1 instead of `step`, so a skipped update does not shift it.  NULL: `step` is used.
  * ---------------------------------------------------------------------------------------- */
 int pgasr_dropout(const float* x, float* y, unsigned long long n, float p, uint64_t seed, uint32_t offset,
                   const float* dact_y, float slope, void* stream);
@@ -342,7 +354,7 @@ int pgasr_dropout(const float* x, float* y, unsigned long long n, float p, uint6
 int pgasr_stream_copy(const void* src, void* dst, unsigned long long bytes, int workgroups, void* stream);
 int pgasr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, unsigned long long n,
                     int step, float lr, float beta1, float beta2, float eps, float weight_decay,
-                    const int32_t* guard0, const int32_t* guard1, void* stream);
+                    const int32_t* guard0, const int32_t* guard1, int32_t* applied, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * N3  feature front end (data.py:44-79): MFCC(40) + delta + delta-delta of torchaudio's defaults

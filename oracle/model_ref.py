@@ -69,12 +69,17 @@ def lstm_flat_weights(p):
     return flat
 
 
-def encoder_forward_torch(p, x, mask, packed=True):
+def encoder_forward_torch(p, x, mask, packed=True, leaky_side=None, return_pre=False):
     """p: dict of tensors; x (B,F,T); mask (B,T) 1/0 -> (B,T,512).
-    Eval mode (no dropout).  model.py:47-56."""
+    Eval mode (no dropout).  model.py:47-56.
+    leaky_side (B,T,512) bool: which side of leaky_relu (model.py:50) each pre-activation is put on, instead of its own
+    sign -- a DISCRETE choice, like an arg-max: a full-size parity test that shares the discrete choices of the device
+    path (tests/test_train_step_gpu.py) passes the device's sides after counting how many differ from the oracle's own.
+    return_pre: also return the pre-activations (B,T,512)."""
     B, Fdim, T = x.shape
     h = instance_norm(x).transpose(1, 2)                      # (B,T,F)
-    h = F.leaky_relu(F.linear(h, p["input_layer.weight"], p["input_layer.bias"]))
+    pre = F.linear(h, p["input_layer.weight"], p["input_layer.bias"])
+    h = F.leaky_relu(pre) if leaky_side is None else torch.where(leaky_side, pre, 0.01 * pre)
     lengths = mask.sum(dim=1).to(torch.int64).cpu()
     lstm = torch.nn.LSTM(D_IN, H, N_LAYERS, bidirectional=True, batch_first=True).to(x.dtype)
     lstm.eval()
@@ -86,7 +91,7 @@ def encoder_forward_torch(p, x, mask, packed=True):
         out, _ = pad_packed_sequence(out, total_length=T, batch_first=True)
     else:
         out, _ = torch.func.functional_call(lstm, sd, (h,))
-    return out
+    return (out, pre) if return_pre else out
 
 
 def head_forward_torch(p, enc_out):

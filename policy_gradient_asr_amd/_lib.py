@@ -45,7 +45,7 @@ SIGNATURES = {
     "pgasr_dropout": (C.c_int, [c_f32p, c_f32p, C.c_ulonglong, C.c_float, C.c_uint64, C.c_uint32, c_f32p, C.c_float, c_ptr]),
     "pgasr_stream_copy": (C.c_int, [c_ptr, c_ptr, C.c_ulonglong, C.c_int, c_ptr]),
     "pgasr_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_ulonglong, C.c_int, C.c_float, C.c_float,
-                                  C.c_float, C.c_float, C.c_float, c_i32p, c_i32p, c_ptr]),
+                                  C.c_float, C.c_float, C.c_float, c_i32p, c_i32p, c_i32p, c_ptr]),
     "pgasr_gemm_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "pgasr_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                  c_f32p, C.c_int, C.c_longlong, c_f32p, C.c_int, C.c_longlong,
@@ -56,6 +56,7 @@ SIGNATURES = {
     "pgasr_gemm_x3w_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_ptr, c_ptr, c_f32p, C.c_int,
                                      c_f32p, c_f32p, C.c_float, c_ptr]),
     "pgasr_gemm_x3w_feed_workspace_bytes": (C.c_size_t, []),
+    "pgasr_gemm_x3w_feed_col_tiles": (C.c_int, [C.c_int]),
     "pgasr_gemm_x3w_feed_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_ptr, c_ptr, c_f32p, C.c_int,
                                           c_f32p, c_ptr, c_ptr, C.c_int, c_ptr, C.c_size_t, c_ptr]),
     "pgasr_feat_frames": (C.c_int, [c_f32p, c_i32p, c_i32p, C.c_int, C.c_longlong, C.c_int, c_f32p, c_ptr]),
@@ -67,8 +68,8 @@ SIGNATURES = {
                                    c_ptr, C.c_size_t, c_ptr]),
     "pgasr_instnorm_stats": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, c_f32p, c_ptr]),
     "pgasr_log_softmax_rows": (C.c_int, [c_f32p, C.c_longlong, C.c_int, c_f32p, c_ptr]),
-    "pgasr_lstm_pack_bytes": (C.c_size_t, [C.c_int]),
-    "pgasr_lstm_pack_weights": (C.c_int, [c_f32p] * 8 + [C.c_int, c_f32p, c_f32p, c_ptr, c_ptr, c_ptr]),
+    "pgasr_lstm_pack_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "pgasr_lstm_pack_weights": (C.c_int, [c_f32p] * 8 + [C.c_int, c_f32p, c_f32p, c_ptr, c_ptr, C.c_int, c_ptr]),
     "pgasr_lstm_unpack_grads": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int] + [c_f32p] * 8 + [C.c_int, c_ptr]),
     "pgasr_lstm_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "pgasr_lstm_error_offset": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
@@ -112,7 +113,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.pgasr_abi_version() != 2:
+    if lib.pgasr_abi_version() != 3:
         raise PgasrError("libpgasr_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -286,7 +286,7 @@ inline size_t beam_lds_bytes(int K, int V) {
 
 // =====================================================================================================================
 // Small-beam search for the training path (reward hypothesis of policy_grad.py:6-8 inside the train step):
-// fp32 device log-probs, beam <= 16, V <= 32, T * beam <= 24576.  ONE WAVE per utterance, no workgroup barrier, no
+// fp32 device log-probs, beam <= 16, V <= 32, T * beam <= 24576 and T <= 4096.  ONE WAVE per utterance, no workgroup barrier, no
 // LDS sort: the generic kernel above spends 24 us per frame in 45 LDS bitonic passes with barriers (24 ms for T = 1000);
 // a frame here is ~800 wave instructions.
 //
@@ -311,6 +311,7 @@ inline size_t beam_lds_bytes(int K, int V) {
 namespace sb {
 constexpr int K_MAX = 16, V_MAX = 32, H = 32768, CH = 32;
 constexpr long long MAX_NODES = 24576;               // T * beam: load factor of the table <= 0.75
+constexpr int MAX_TOKENS = 4096;                     // a hypothesis has at most T tokens and is staged in the 8 KB `frames` region (beam < 6 would admit longer T)
 constexpr unsigned ROOT = 0x8000u, NONE = 0xFFFFu, BAD_ID = 0x0FFFFFFFu;
 constexpr unsigned KEYMASK = 0x01FFFFFFu;
 constexpr size_t LDS_TABLE = (size_t)H * 4;          // 128 KB
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
 
     // ---- result: ancestors of the best entry, in order, optionally through collapse_fn ----
     __syncthreads();
-    unsigned short* tmp = reinterpret_cast<unsigned short*>(frames);      // up to 4096 tokens: T <= MAX_NODES / beam
+    unsigned short* tmp = reinterpret_cast<unsigned short*>(frames);      // 8 KB = 4096 tokens: the dispatch admits T <= MAX_TOKENS only
     unsigned cur = (unsigned)__builtin_amdgcn_readlane((int)id, 0);
     int n = 0;
     if (nb > 0) {
@@ -588,7 +589,7 @@ extern "C" int pgasr_ctc_beam_search(const void* log_probs, int is_f64, long lon
     if ((long long)T * beam + 1 >= (1ll << 24)) return PGASR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int collapse = flags & 1;
-    if (!is_f64 && !(flags & 2) && beam <= sb::K_MAX && V <= sb::V_MAX && (long long)T * beam <= sb::MAX_NODES) {
+    if (!is_f64 && !(flags & 2) && beam <= sb::K_MAX && V <= sb::V_MAX && (long long)T * beam <= sb::MAX_NODES && T <= sb::MAX_TOKENS) {
         // training path: one wave per utterance, trie and candidate lists in LDS, no workspace traffic
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sb::beam_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb::LDS_BYTES);
         PGASR_LAUNCH_KERNEL(sb::beam_small_kernel, dim3(B), dim3(64), sb::LDS_BYTES, st, (const float*)log_probs, stride_t, stride_b,

@@ -333,6 +333,279 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_x3w_kernel(DmaGemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same product on a 256 x 256 tile with 128 x 128 per wave (round 3).  What the 256 x 128 kernel above saturates first
+// is not the MFMA pipe (35 % busy) but instruction ISSUE on its two waves per SIMD: per 12 MFMAs a wave reads 8 KB of
+// fragments and splits two 32 x 8 fp32 A fragments into bf16 hi / lo (~56 VALU instructions), and an MFMA itself holds
+// the SIMD's vector issue for 8 of its 32 cycles.  A 128 x 128 wave tile (4 waves, one per SIMD, the 256 accumulator
+// registers in the unified VGPR/AGPR file) does 48 MFMAs per 16-deep k-step on 16 KB of fragments and four A splits:
+// half the LDS bytes and half the VALU per MFMA, and no second wave competing for the SIMD's issue slots.
+//   * stage = ONE 16-deep k-step: A 256 x 16 fp32 (16 KB) + two W planes 256 x 16 bf16 (8 KB each) = 32 KB, four stages
+//     (128 KB), every wave issues exactly 8 LDS-DMA instructions per k-step, counted s_waitcnt vmcnt(16): up to three
+//     k-steps (96 KB) in flight per CU;
+//   * A rows are 64 B (4 chunks, chunk ^= (row >> 2) & 3), plane rows 32 B (2 chunks, chunk ^= (row >> 3) & 1): any lane
+//     group of a ds_read_b128 covers the 16 slots of a 256-byte bank row once;
+//   * ONE barrier per k-step, placed BEFORE the last quarter of the step's MFMAs: the wave waits for its DMA pieces of
+//     the next k-step, meets the others, refills the stage everybody has finished reading, issues the next k-step's
+//     fragment reads (W fragments double-buffered in registers) -- and only then issues row tile 3's twelve MFMAs, which
+//     cover the LDS latency and the first split of the next step;
+//   * accumulation over K is ONE chain per tile (the 256 x 128 kernel's fixed-order K-quarters would need a second set
+//     of 256 accumulators); only the feed's first tiles are computed as four parallel K-quarters, parked in the slab
+//     area and summed in index order, and the sequential order of the same product runs the SAME kernel with the same
+//     decomposition, so fed and sequential results stay bit-identical (functional.py).
+// Preconditions: K % 32 == 0 (k-steps are taken in pairs), N % 256 == 0, lda % 4 == 0, 16-byte aligned operands.
+// ------------------------------------------------------------------------------------------------------------------
+namespace w256 {
+constexpr int TM = 256, TN = 256, TK = 16, NST = 4, THREADS = 256;
+constexpr int A_BYTES = TM * TK * 4;                 // 16 KB raw fp32
+constexpr int P_BYTES = TN * TK * 2;                 // 8 KB per bf16 plane
+constexpr int STAGE_BYTES = A_BYTES + 2 * P_BYTES;   // 32 KB
+constexpr int SLAB_FLOATS = 256 * THREADS;           // one parked accumulator set (256 registers x 256 threads) = 256 KB
+
+struct RawA { u32x4_t a[4][2]; };          // row tile x chunk (8 fp32 of one row)
+struct RawB { u32x4_t h[4], l[4]; };       // column tile: hi / lo plane (8 bf16 of one row)
+
+__device__ __forceinline__ void read_a(RawA& r, unsigned p0, unsigned p1, unsigned p2, unsigned p3) {
+    asm volatile("ds_read_b128 %0, %8\n\t"
+                 "ds_read_b128 %1, %9\n\t"
+                 "ds_read_b128 %2, %10\n\t"
+                 "ds_read_b128 %3, %11\n\t"
+                 "ds_read_b128 %4, %12\n\t"
+                 "ds_read_b128 %5, %13\n\t"
+                 "ds_read_b128 %6, %14\n\t"
+                 "ds_read_b128 %7, %15"
+                 : "=&v"(r.a[0][0]), "=&v"(r.a[0][1]), "=&v"(r.a[1][0]), "=&v"(r.a[1][1]),
+                   "=&v"(r.a[2][0]), "=&v"(r.a[2][1]), "=&v"(r.a[3][0]), "=&v"(r.a[3][1])
+                 : "v"(p0), "v"(p0 ^ 16u), "v"(p1), "v"(p1 ^ 16u), "v"(p2), "v"(p2 ^ 16u), "v"(p3), "v"(p3 ^ 16u)
+                 : "memory");
+}
+__device__ __forceinline__ void read_b(RawB& r, unsigned p0, unsigned p1, unsigned p2, unsigned p3) {
+    static_assert(P_BYTES == 8192, "plane offset is spelled in the asm below");
+    asm volatile("ds_read_b128 %0, %8\n\t"
+                 "ds_read_b128 %1, %8 offset:8192\n\t"
+                 "ds_read_b128 %2, %9\n\t"
+                 "ds_read_b128 %3, %9 offset:8192\n\t"
+                 "ds_read_b128 %4, %10\n\t"
+                 "ds_read_b128 %5, %10 offset:8192\n\t"
+                 "ds_read_b128 %6, %11\n\t"
+                 "ds_read_b128 %7, %11 offset:8192"
+                 : "=&v"(r.h[0]), "=&v"(r.l[0]), "=&v"(r.h[1]), "=&v"(r.l[1]),
+                   "=&v"(r.h[2]), "=&v"(r.l[2]), "=&v"(r.h[3]), "=&v"(r.l[3])
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                 : "memory");
+}
+__device__ __forceinline__ void wait_frags(RawA& a, RawB& b) {     // claims the registers the reads above are filling
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a.a[0][0]), "+v"(a.a[0][1]), "+v"(a.a[1][0]), "+v"(a.a[1][1]),
+                   "+v"(a.a[2][0]), "+v"(a.a[2][1]), "+v"(a.a[3][0]), "+v"(a.a[3][1]),
+                   "+v"(b.h[0]), "+v"(b.l[0]), "+v"(b.h[1]), "+v"(b.l[1]),
+                   "+v"(b.h[2]), "+v"(b.l[2]), "+v"(b.h[3]), "+v"(b.l[3])
+                 :: "memory");
+}
+
+template <bool FEED>
+__global__ __launch_bounds__(THREADS) void gemm_x3w256_kernel(DmaGemmArgs g) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];   // the ONLY LDS object
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int nk = g.K / TK;
+    if (FEED && g.xcc_busy) {       // a workgroup on one of the sweep's XCDs leaves at once (placement is read, not assumed)
+        const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;
+        if (__hip_atomic_load(g.xcc_busy + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    }
+  for (;;) {
+    int tbx, tby;
+    int kt0 = 0, kt1 = nk, qpart = -1;      // k-step range of this work item; qpart >= 0: one quarter of a split tile
+    unsigned tile = 0;
+    if (FEED) {
+        unsigned* mailbox = reinterpret_cast<unsigned*>(smem + NST * STAGE_BYTES);   // 16 bytes past the stages
+        if (tid == 0) *mailbox = __hip_atomic_fetch_add(g.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned t = *mailbox;
+        __syncthreads();
+        const unsigned S = (unsigned)g.split_tiles, ntot = (unsigned)g.mt_count * (unsigned)g.nt_count;
+        if (t >= ntot + 3u * S) return;             // 4 S quarter items, then the remaining ntot - S whole tiles
+        if (t < 4u * S) { tile = t >> 2; qpart = (int)(t & 3u); kt0 = qpart * (nk >> 2); kt1 = kt0 + (nk >> 2); }
+        else tile = t - 3u * S;
+        const int half = g.nt_count >> 1, grp = (int)(tile / (unsigned)g.nt_count), j = (int)(tile % (unsigned)g.nt_count);
+        tbx = j;
+        tby = ((j < half) != (g.order != 0)) ? grp : g.mt_count - 1 - grp;
+    } else {
+        swizzled_tile(tbx, tby);
+    }
+    const int m0 = tby * TM, n0 = tbx * TN;
+
+    // ---- per-lane DMA sources (k offset added per k-step): wave w moves A pieces 4j + w (16 rows each) and plane pieces 4j + w (32 rows each)
+    const float* pa[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 16 * (4 * j + w) + (lane >> 2), cp = lane & 3, c = cp ^ ((row >> 2) & 3);
+        int gm = m0 + row; gm = gm < g.M ? gm : g.M - 1;
+        pa[j] = g.A + (size_t)gm * g.lda + c * 4;
+    }
+    const unsigned short *ph[2], *pl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 32 * (4 * j + w) + (lane >> 1), cp = lane & 1, c = cp ^ ((row >> 3) & 1);
+        const size_t o = (size_t)(n0 + row) * g.K + c * 8;
+        ph[j] = g.Whi + o; pl[j] = g.Wlo + o;
+    }
+    auto issue = [&](int kt, int stage) {      // ALWAYS 8 wave-instructions (k clamped), so the counted waits are exact
+        const int k0 = (kt < nk ? kt : nk - 1) * TK;
+        unsigned char* sa = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16(pa[j] + k0, sa + (4 * j + w) * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma16(ph[j] + k0, sa + A_BYTES + (4 * j + w) * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma16(pl[j] + k0, sa + A_BYTES + P_BYTES + (4 * j + w) * 1024);
+    };
+
+    // ---- per-lane fragment read offsets inside a stage ----
+    const int fr = lane & 31, fh = lane >> 5;
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wm * 128 + i * 32 + fr, n = wn * 128 + i * 32 + fr;
+        offA[i] = (unsigned)(row * 64 + (((fh * 2) ^ ((row >> 2) & 3)) * 16));        // second chunk: ^ 16
+        offB[i] = (unsigned)(A_BYTES + n * 32 + ((fh ^ ((n >> 3) & 1)) * 16));        // lo plane: + P_BYTES
+    }
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    RawA ra;
+    RawB rb0, rb1;
+#pragma unroll
+    for (int s = 0; s < NST; ++s) issue(kt0 + s, s);
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // my pieces of the first k-step have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_a(ra, lds0 + offA[0], lds0 + offA[1], lds0 + offA[2], lds0 + offA[3]);
+    read_b(rb0, lds0 + offB[0], lds0 + offB[1], lds0 + offB[2], lds0 + offB[3]);
+
+    // one k-step: fragments of step kt are (being) read into ra / BCUR; BNXT receives the next step's W fragments.
+    // sched_barrier(0) pins the three regions (hipcc otherwise hoists the barrier to the top of the step and sinks the
+    // next step's fragment reads behind the last MFMA, exposing their latency); inside a region the scheduler is free
+    // to interleave the A splits with the MFMAs.
+    auto kstep = [&](const int kt, RawB& bcur, RawB& bnxt) {
+        wait_frags(ra, bcur);
+        bf16x8_t ah[4], al[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split8(ra.a[i][0], ra.a[i][1], ah[i], al[i]);
+        bf16x8_t bh[4], bl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bh[j] = __builtin_bit_cast(bf16x8_t, bcur.h[j]); bl[j] = __builtin_bit_cast(bf16x8_t, bcur.l[j]); }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        // the next k-step: its DMA pieces (mine) have landed, everybody's are visible behind the barrier, and the stage of
+        // step kt -- read into registers by every wave before it got here -- is free for step kt + 4
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int rel = kt - kt0;
+        const unsigned sb = lds0 + (unsigned)((rel + 1) & 3) * STAGE_BYTES;
+        read_a(ra, sb + offA[0], sb + offA[1], sb + offA[2], sb + offA[3]);
+        read_b(bnxt, sb + offB[0], sb + offB[1], sb + offB[2], sb + offB[3]);
+        issue(kt + NST, rel & 3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[3][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[3], bh[j], acc[3][j], 0, 0, 0);
+            acc[3][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[3], bl[j], acc[3][j], 0, 0, 0);
+            acc[3][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[3], bh[j], acc[3][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int kt = kt0; kt < kt1; kt += 2) {       // k-steps come in pairs (K % 32 == 0; a quarter of K % 128 == 0 is even too)
+        kstep(kt, rb0, rb1);
+        kstep(kt + 1, rb1, rb0);
+    }
+    wait_frags(ra, rb0);                           // the reads issued for the step behind the last one (discarded)
+
+    if (FEED && qpart >= 0) {
+        // one quarter of a split tile: park the accumulators (thread-major: a wave instruction stores 256 contiguous
+        // bytes) write-through, count the arrival; the LAST of the four sums the quarters in index order and goes on to
+        // the epilogue, the others take their next work item
+        __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(g.slabs, 0, (int)((size_t)g.split_tiles * 4 * SLAB_FLOATS * 4), 0x00020000);
+        const unsigned sbq = (tile * 4u + (unsigned)qpart) * 256u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), srs, ((sbq + (unsigned)((i * 4 + j) * 16 + r)) * 256u + (unsigned)tid) * 4u, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* mailbox = reinterpret_cast<unsigned*>(smem + NST * STAGE_BYTES);
+        if (tid == 0) *mailbox = __hip_atomic_fetch_add(g.arrive + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned before = *mailbox;
+        __syncthreads();
+        if (before != 3u) continue;
+        // total = ((q0 + q1) + q2) + q3, whoever arrives last
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                            srs, (((tile * 4u + (unsigned)qq) * 256u + (unsigned)((i * 4 + j) * 16 + r)) * 256u + (unsigned)tid) * 4u, 0, 16));
+                        t = qq == 0 ? v : t + v;
+                    }
+                    acc[i][j][r] = t;
+                }
+    }
+
+    // epilogue: 32x32 accumulator layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int cl = lane & 31, rq = lane >> 5;
+    __amdgpu_buffer_rsrc_t crs;
+    if (FEED) crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)((size_t)g.M * g.ldc * 4), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 128 + j * 32 + cl;
+            const float bsum = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+                if (m >= g.M) continue;
+                float v = acc[i][j][r] + bsum;
+                if (g.dact_y) v *= (g.dact_y[(size_t)m * g.ldc + n] > 0.f ? 1.f : g.slope);
+                if (FEED) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crs, (unsigned)(((size_t)m * g.ldc + n) * 4), 0, 16);
+                else g.C[(size_t)m * g.ldc + n] = v;
+            }
+        }
+    if (!FEED) return;
+    // the tile's stores have reached memory (vmcnt(0) in every wave, then the barrier) before it is counted; the
+    // barrier also retires every DMA of this tile before the next one reuses the stages
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        __hip_atomic_fetch_add(g.tiles_done + (tbx < (g.nt_count >> 1) ? 0 : g.mt_count) + tby, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+}  // namespace w256
+
 // fp32 (rows x cols, leading dim ld) -> dense bf16 hi / lo planes; transpose: planes are (cols x rows)
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int rows, int cols, int ld,
                                                            int transpose, unsigned short* __restrict__ hi,
@@ -360,8 +633,21 @@ extern "C" int pgasr_split_bf16_planes(const float* src, int rows, int cols, int
     return PGASR_OK;
 }
 
+// PGASR_X3W_TILE=128 in the environment keeps the round-1 256 x 128 kernel (A/B measurements only)
+static bool x3w_force_128() {
+    static const bool v = [] { const char* e = getenv("PGASR_X3W_TILE"); return e && e[0] == '1' && e[1] == '2' && e[2] == '8'; }();
+    return v;
+}
 static int x3w_quarters(int K) { return (K >= 1024 && K % (4 * TK) == 0) ? 4 : 1; }   // a quarter of >= 8 k-tiles (K = 512 in quarters: step +0.05 ms)
 constexpr int FEED_SPLIT_MAX = 64;       // split tiles per feed: 4 x 64 slabs of 128 KB = 32 MB of workspace
+
+// Column tiles per direction half that a feed of an N-column product counts in tiles_done (the consumer's `fed_need`):
+// N / 2 / 256 on the 256 x 256 tile, N / 2 / 128 on the 256 x 128 one; 0: not a feedable width.
+extern "C" int pgasr_gemm_x3w_feed_col_tiles(int N) {
+    if (N <= 0 || N % (2 * TN)) return 0;
+    if (N % (2 * w256::TN) == 0 && !x3w_force_128()) return N / (2 * w256::TN);
+    return N / (2 * TN);
+}
 
 extern "C" size_t pgasr_gemm_x3w_feed_workspace_bytes(void) { return 1024 + (size_t)FEED_SPLIT_MAX * 4 * 64 * 512 * 4; }
 
@@ -373,6 +659,15 @@ extern "C" int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, 
         return PGASR_ERR_UNSUPPORTED;
     const unsigned gy = (unsigned)((M + TM - 1) / TM);
     if (gy > 65535u) return PGASR_ERR_UNSUPPORTED;
+    if (N % w256::TN == 0 && !x3w_force_128()) {     // the 256 x 256 tile (one accumulation chain over K per tile)
+        const size_t lds2 = (size_t)w256::NST * w256::STAGE_BYTES;
+        if (hipFuncSetAttribute((const void*)w256::gemm_x3w256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+            return PGASR_ERR_LAUNCH;
+        DmaGemmArgs g2{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, dact_y, slope, nullptr, nullptr, nullptr, 0, 0, 0, 1, 0, nullptr, nullptr};
+        PGASR_LAUNCH_KERNEL(w256::gemm_x3w256_kernel<false>, dim3((unsigned)(N / w256::TN), gy), dim3(w256::THREADS), lds2, (hipStream_t)stream, g2);
+        PGASR_CHECK_LAUNCH();
+        return PGASR_OK;
+    }
     const size_t lds = (size_t)NST * STAGE_BYTES;   // 144 KB of the CU's 160 KB: opt in per call (idempotent, no state kept)
     if (hipFuncSetAttribute((const void*)gemm_x3w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
@@ -402,11 +697,36 @@ extern "C" int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int 
     if ((K % TK) || (N % (2 * TN)) || (lda & 3) || (((size_t)A) & 15) || (((size_t)Whi) & 15) || (((size_t)Wlo) & 15))
         return PGASR_ERR_UNSUPPORTED;
     if ((size_t)M * ldc * 4 >= ((size_t)1 << 31)) return PGASR_ERR_UNSUPPORTED;      // buffer-addressed stores
+    hipStream_t st = (hipStream_t)stream;
+    if (pgasr_gemm_x3w_feed_col_tiles(N) == N / (2 * w256::TN)) {
+        // 256 x 256 tiles: the same queue, counters and quarter protocol, slabs of 256 KB
+        const int mt2 = (M + w256::TM - 1) / w256::TM, nt2 = N / w256::TN;
+        const size_t lds2 = (size_t)w256::NST * w256::STAGE_BYTES + 16;
+        if (hipFuncSetAttribute((const void*)w256::gemm_x3w256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+            return PGASR_ERR_LAUNCH;
+        if (hipMemsetAsync(workspace, 0, 1024, st) != hipSuccess) return PGASR_ERR_LAUNCH;
+        const int quarters2 = x3w_quarters(K);
+        int split2 = 0;
+        if (quarters2 == 4) {
+            const size_t room = (workspace_bytes - 1024) / ((size_t)4 * w256::SLAB_FLOATS * 4);
+            split2 = 16 * nt2;
+            if (split2 > FEED_SPLIT_MAX) split2 = FEED_SPLIT_MAX;
+            if ((size_t)split2 > room) split2 = (int)room;
+            if (split2 > mt2 * nt2) split2 = mt2 * nt2;
+        }
+        DmaGemmArgs g2{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, nullptr, 0.f, (unsigned*)workspace, xcc_busy, tiles_done, mt2, nt2, order,
+                       quarters2, split2, (float*)((char*)workspace + 1024), (unsigned*)workspace + 64};
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) g2.xcc_busy = nullptr;
+            PGASR_LAUNCH_KERNEL(w256::gemm_x3w256_kernel<true>, dim3(256), dim3(w256::THREADS), lds2, st, g2);
+            PGASR_CHECK_LAUNCH();
+        }
+        return PGASR_OK;
+    }
     const int mt = (M + TM - 1) / TM, nt = N / TN;
     const size_t lds = (size_t)NST * STAGE_BYTES + 16;
     if (hipFuncSetAttribute((const void*)gemm_x3w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
-    hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(workspace, 0, 1024, st) != hipSuccess) return PGASR_ERR_LAUNCH;   // tile counter + arrival counters
     // the first tile groups (16 time-ordered groups, at most FEED_SPLIT_MAX tiles and what the workspace holds) are split
     // into K-quarters: the sweep is waiting for exactly these

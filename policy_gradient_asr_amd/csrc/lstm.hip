@@ -9,7 +9,13 @@
 // per CU, each owning 16 hidden units, with its weight slice resident in registers (64 VGPRs of
 // bf16 hi/lo pairs per lane) for the whole sweep.  Matrix products run on
 // v_mfma_f32_16x16x32_bf16 as hi*hi + hi*lo + lo*hi with fp32 accumulation (~15-16 mantissa bits
-// per operand; measured 1e-5 relative on layer outputs against fp64).  Per step the members
+// per operand; measured 1e-5 relative on layer outputs against fp64).  The kernels are templates on the
+// number of bf16 PLANES an fp32 operand is split into: NP = 2 is that default; NP = 3 (flags bit 1, the
+// "f32" precision mode of the host layer) is the fp32-faithful variant the reference's arithmetic asks
+// for (model.py:38-44: nn.LSTM in torch's default fp32): hi/mid/lo planes and the six products
+// hh + hm + mh + hl + lh + mm, i.e. every term down to 2^-24 of the product -- 96 weight VGPRs
+// per lane instead of 64, 48 MFMAs per step instead of 24 (+~400 cycles), 24 KiB instead of 16 KiB polled
+// per forward step.  Per step the members
 // exchange h_t (forward, 16 KiB) or partial dh sums (backward, 16 KiB read per member) through
 // global memory using self-validating words (below): no flag, counter, fence or drain sits on
 // the dependent chain, results cannot depend on dispatch order, XCD placement or the order in
@@ -134,6 +140,44 @@ __device__ __forceinline__ void split_tagged(float x, unsigned tb, unsigned shor
 __device__ __forceinline__ void split_plain(float x, unsigned short& hi, unsigned short& lo) {
     hi = f2bf(x);
     lo = f2bf(x - bf2f(hi));
+}
+// NP planes: plane p = bf16 of what the planes before it left over (each subtraction is exact in fp32)
+template <int NP>
+__device__ __forceinline__ void split_planes_tagged(float x, unsigned tb, unsigned short (&pl)[NP]) {
+    float r = x;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        pl[p] = (unsigned short)((f2bf(r) & 0xFFFEu) | tb);
+        r -= bf2f(pl[p]);
+    }
+}
+template <int NP>
+__device__ __forceinline__ void split_planes_plain(float x, unsigned short (&pl)[NP]) {
+    float r = x;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        pl[p] = f2bf(r);
+        r -= bf2f(pl[p]);
+    }
+}
+// acc += A x B for operands given as NP bf16 planes: every product term of weight >= 2^-24 relative.
+// NP = 2: hh + hl + lh (the order the sweeps have always used); NP = 3: hh + hm + mh + hl + lh + mm.
+template <int NP>
+__device__ __forceinline__ void mfma_planes_pair(const bf16x8 (&A0)[NP], const bf16x8 (&A1)[NP], const bf16x8 (&Bp)[NP], f32x4 (&acc)[2]) {
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0[0], Bp[0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[0], Bp[0], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0[0], Bp[1], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[0], Bp[1], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0[1], Bp[0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[1], Bp[0], acc[1], 0, 0, 0);
+    if constexpr (NP == 3) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0[0], Bp[2], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[0], Bp[2], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0[2], Bp[0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[2], Bp[0], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0[1], Bp[1], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[1], Bp[1], acc[1], 0, 0, 0);
+    }
 }
 __device__ __forceinline__ unsigned or4(u32x4 v) { return (v.x | v.y) | (v.z | v.w); }
 // non-zero iff some word's (bit0, bit16) differs from the wanted pattern
@@ -395,8 +439,9 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_base) {
 // k-quarter [64w, 64w+64) of h_{t-1} into all 64 gate rows of the workgroup (4 MFMA tiles x 2
 // k-steps x 3 split terms); the four partial tiles are summed through LDS and each compute thread
 // finishes ONE (unit, utterance) cell.
-// exchange slot per cluster: [parity 2][kc 32][n 16][hl 2][8 bf16]; member g owns kc = 2g, 2g+1.
+// exchange slot per cluster: [parity 2][kc 32][n 16][plane NP][8 bf16]; member g owns kc = 2g, 2g+1.
 // ------------------------------------------------------------------------------------------
+template <int NP>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
     const int cl = blockIdx.x % a.NCL8, g = blockIdx.x / a.NCL8;
     if (cl >= 2 * a.NBG) return;
@@ -418,21 +463,21 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
     if (tid == 0) { LDS_FLAG_SET(s_abort, 0); LDS_FLAG_SET(s_same, 0); }
     __syncthreads();
 
-    // weight slices -> registers: tile m (units 4(4g+m)..+3, row = 4*uu+gate), k-steps 2w, 2w+1
-    bf16x8 Whi[4][2], Wlo[4][2];
+    // weight slices -> registers: tile m (units 4(4g+m)..+3, row = 4*uu+gate), k-steps 2w, 2w+1, NP planes each
+    bf16x8 W[4][2][NP];
     if (w < IO_WAVE) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const u32x4* wp = a.wpack + ((size_t)(dir * 64 + 4 * g + m) * 8) * 2 * 64;
+            const u32x4* wp = a.wpack + ((size_t)(dir * 64 + 4 * g + m) * 8) * NP * 64;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                Whi[m][i] = __builtin_bit_cast(bf16x8, wp[((2 * w + i) * 2 + 0) * 64 + lane]);
-                Wlo[m][i] = __builtin_bit_cast(bf16x8, wp[((2 * w + i) * 2 + 1) * 64 + lane]);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) W[m][i][pl] = __builtin_bit_cast(bf16x8, wp[((2 * w + i) * NP + pl) * 64 + lane]);
             }
         }
     }
-    constexpr unsigned SLOT = 32 * 16 * 2 * 16;       // bytes per parity slot (16 KiB)
-    unsigned char* xb = a.xbuf + (size_t)cl * (2 * SLOT);
+    constexpr unsigned SLOT = 32 * 16 * NP * 16;      // bytes per parity slot (16 KiB; 24 KiB with three planes)
+    unsigned char* xb = a.xbuf + (size_t)cl * (2 * (32 * 16 * 3 * 16));      // cluster blocks are laid out for three planes (lstm_ws_layout)
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)(2 * SLOT), 0x00020000);
     const bool same_xcd = cluster_same_xcd(a, cl, g, tid, s_same, s_abort);
 
@@ -542,23 +587,29 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
                 // fresh word of epoch e: (bit0, bit16) = (e, 1-e); the two halves of a word are written by
                 // different lanes (2-byte stores), so BOTH bits are checked
                 const unsigned want = (((step - 1) >> 1) & 1) ? 0x00000001u : 0x00010000u;
-                u32x4 vh[2], vl[2];
+                u32x4 vp[2][NP];
                 auto issue_loads = [&]() {
                     POLL_FENCE();
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        const unsigned off = pbase + (unsigned)((((4 * (2 * w + i) + q) * 16 + n) * 2) * 16);
-                        vh[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
-                        vl[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 16);
+                        const unsigned off = pbase + (unsigned)((((4 * (2 * w + i) + q) * 16 + n) * NP) * 16);
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl) vp[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16 * pl, 0, 16);
                     }
                 };
 #ifdef PGASR_LSTM_DIAG
-                if (a.diag & 8) { vh[0] = vh[1] = vl[0] = vl[1] = (u32x4){0u, 0u, 0u, 0u}; } else
+                if (a.diag & 8) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl) vp[i][pl] = (u32x4){0u, 0u, 0u, 0u};
+                } else
 #endif
                 issue_loads();            // the operand loads ARE the poll
                 SpinGuard sg;
                 while (true) {
-                    const unsigned bad = (bad4(vh[0], want) | bad4(vl[0], want)) | (bad4(vh[1], want) | bad4(vl[1], want));
+                    unsigned bad = (bad4(vp[0][0], want) | bad4(vp[0][1], want)) | (bad4(vp[1][0], want) | bad4(vp[1][1], want));
+                    if constexpr (NP == 3) bad |= bad4(vp[0][2], want) | bad4(vp[1][2], want);
                     if (!__any(bad != 0)) break;
 #ifdef PGASR_LSTM_DIAG
                     if (a.diag & 12) break;
@@ -567,11 +618,11 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
                     issue_loads();
                 }
                 STAMP(1);
-                bf16x8 Hhi[2], Hlo[2];
+                bf16x8 Hp[2][NP];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    Hhi[i] = __builtin_bit_cast(bf16x8, vh[i]);
-                    Hlo[i] = __builtin_bit_cast(bf16x8, vl[i]);
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) Hp[i][pl] = __builtin_bit_cast(bf16x8, vp[i][pl]);
                 }
                 // Two tile pairs, each pair's 12 MFMAs interleaved, and the first pair's partial tiles written to LDS while the
                 // second pair is multiplied: ds_write_b128 moves only ~80 B/clk per CU, i.e. the 16 KiB of partials are ~200
@@ -583,14 +634,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
 #pragma unroll
                     for (int m2 = 0; m2 < 2; ++m2) acc[m2] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                        for (int m2 = 0; m2 < 2; ++m2) acc[m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[2 * half + m2][i], Hhi[i], acc[m2], 0, 0, 0);
-#pragma unroll
-                        for (int m2 = 0; m2 < 2; ++m2) acc[m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[2 * half + m2][i], Hlo[i], acc[m2], 0, 0, 0);
-#pragma unroll
-                        for (int m2 = 0; m2 < 2; ++m2) acc[m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wlo[2 * half + m2][i], Hhi[i], acc[m2], 0, 0, 0);
-                    }
+                    for (int i = 0; i < 2; ++i) mfma_planes_pair<NP>(W[2 * half][i], W[2 * half + 1][i], Hp[i], acc);
 #pragma unroll
                     for (int m2 = 0; m2 < 2; ++m2)
                         *reinterpret_cast<float4*>(&part[step & 1][(w * 16 + n) * PROW + (4 * (2 * half + m2) + q) * 4]) =
@@ -628,19 +672,19 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
 #endif
             {
                 // publish h_t (also after the last step: nobody reads that slot, and lstm_prepare_kernel resets it): each cell
-                // thread writes its own bf16 hi and lo (2-byte stores); layout [kc = unit/8][n][hl][unit%8] of this member's 1-KiB block
+                // thread writes its own bf16 planes (2-byte stores); layout [kc = unit/8][n][plane][unit%8] of this member's block
                 const unsigned e = (unsigned)(step >> 1) & 1u;
                 const unsigned tb = (pu & 1) ? (1u - e) : e;
-                unsigned short hi, lo;
-                split_tagged(h, tb, hi, lo);
-                const unsigned off = (unsigned)(step & 1) * SLOT + (unsigned)g * 1024u +
-                                     (unsigned)((((pu >> 3) * 16 + pn) * 2) * 16 + (pu & 7) * 2);
+                unsigned short hp[NP];
+                split_planes_tagged<NP>(h, tb, hp);
+                const unsigned off = (unsigned)(step & 1) * SLOT + (unsigned)g * (512u * NP) +
+                                     (unsigned)((((pu >> 3) * 16 + pn) * NP) * 16 + (pu & 7) * 2);
                 if (same_xcd) {
-                    __builtin_amdgcn_raw_buffer_store_b16(hi, rsrc, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b16(lo, rsrc, off + 16, 0, 0);
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) __builtin_amdgcn_raw_buffer_store_b16(hp[pl], rsrc, off + 16 * pl, 0, 0);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b16(hi, rsrc, off, 0, 16);
-                    __builtin_amdgcn_raw_buffer_store_b16(lo, rsrc, off + 16, 0, 16);
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) __builtin_amdgcn_raw_buffer_store_b16(hp[pl], rsrc, off + 16 * pl, 0, 16);
                 }
             }
             STAMP(5);
@@ -673,6 +717,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
 //   4. publishes that partial: [src g][n 16][unit 256] fp32 = 16 KiB, 4 x 16-B stores per lane.
 // Exchange read per workgroup and step: 16 KiB (a dgates all-gather would be 64 KiB).
 // ------------------------------------------------------------------------------------------
+template <int NP>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     const int cl = blockIdx.x % a.NCL8, g = blockIdx.x / a.NCL8;
     if (cl >= 2 * a.NBG) return;
@@ -684,7 +729,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     const int unit = 16 * g + pu;
     const int T = a.T, B = a.B;
 
-    __shared__ __attribute__((aligned(16))) unsigned short dgl[2 * 16 * 2 * 64];   // [buf][n][hl][64 r' local]
+    __shared__ __attribute__((aligned(16))) unsigned short dgl[2 * 16 * NP * 64];  // [buf][n][plane][64 r' local]
     __shared__ __attribute__((aligned(16))) float4 sg_[BWD_RING][256];             // saved gate activations ring, by cell id
     __shared__ __attribute__((aligned(16))) float sct[BWD_RING][256];              // c_t ring (c_prev of step s = c_t of step s+1)
     __shared__ __attribute__((aligned(16))) float sdy[BWD_RING][256];              // dout ring
@@ -695,15 +740,15 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     __syncthreads();
 
     // A operand tiles: output units 16*(4w+mt)..+15 (rows), k = own gate rows r' = 64g + 32i + ..
-    bf16x8 Whi[4][2], Wlo[4][2];
+    bf16x8 W[4][2][NP];
     if (w < IO_WAVE) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const u32x4* wp = a.wpack + ((size_t)(dir * 16 + 4 * w + mt) * 32) * 2 * 64;
+            const u32x4* wp = a.wpack + ((size_t)(dir * 16 + 4 * w + mt) * 32) * NP * 64;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                Whi[mt][i] = __builtin_bit_cast(bf16x8, wp[((2 * g + i) * 2 + 0) * 64 + lane]);
-                Wlo[mt][i] = __builtin_bit_cast(bf16x8, wp[((2 * g + i) * 2 + 1) * 64 + lane]);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) W[mt][i][pl] = __builtin_bit_cast(bf16x8, wp[((2 * g + i) * NP + pl) * 64 + lane]);
             }
         }
     }
@@ -799,7 +844,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
         auto compute_step = [&](const int step, const bool first) -> int {
             const int t = step_t(step);
             float4 d = make_float4(0, 0, 0, 0);
-            unsigned short* dbuf = &dgl[(step & 1) * (16 * 2 * 64)];
+            unsigned short* dbuf = &dgl[(step & 1) * (16 * NP * 64)];
             // everything that does not need the incoming dh is done BEFORE the poll (the rows of this step have
             // been in the LDS ring since the previous barrier): after the hand-off only five multiply-adds remain
             const bool active = t < len;
@@ -864,23 +909,25 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
             else { d = make_float4(0, 0, 0, 0); carry = dh_rec; }
             dbs.x += d.x; dbs.y += d.y; dbs.z += d.z; dbs.w += d.w;
             {
-                unsigned short hi[4], lo[4];
-                split_plain(d.x, hi[0], lo[0]); split_plain(d.y, hi[1], lo[1]);
-                split_plain(d.z, hi[2], lo[2]); split_plain(d.w, hi[3], lo[3]);
-                unsigned short* dst = &dbuf[(pn * 2) * 64 + pu * 4];      // [n][hl][r' local = 4*pu + gate]
-                *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
-                *reinterpret_cast<uint2*>(dst + 64) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+                unsigned short px[NP], py[NP], pz[NP], pw[NP];
+                split_planes_plain<NP>(d.x, px); split_planes_plain<NP>(d.y, py);
+                split_planes_plain<NP>(d.z, pz); split_planes_plain<NP>(d.w, pw);
+                unsigned short* dst = &dbuf[(pn * NP) * 64 + pu * 4];      // [n][plane][r' local = 4*pu + gate]
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    *reinterpret_cast<uint2*>(dst + 64 * pl) = make_uint2(px[pl] | ((unsigned)py[pl] << 16), pz[pl] | ((unsigned)pw[pl] << 16));
             }
             rdg[step & 1][tid] = d;      // written to HBM by the storer wave after the barrier
             LDS_BARRIER();
             const int aborted = LDS_FLAG_GET(s_abort);       // read behind the barrier, used at the end of the step
             {
                 // (also after the last step: nobody reads that slot, and lstm_prepare_kernel resets it)
-                bf16x8 Dhi[2], Dlo[2];
+                bf16x8 Dp[2][NP];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    Dhi[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&dbuf[(n * 2 + 0) * 64 + 32 * i + 8 * q]));
-                    Dlo[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&dbuf[(n * 2 + 1) * 64 + 32 * i + 8 * q]));
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl)
+                        Dp[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&dbuf[(n * NP + pl) * 64 + 32 * i + 8 * q]));
                 }
                 const unsigned e = (unsigned)(step >> 1) & 1u;
                 const unsigned tag = e ? 0x1u : 0x2u;       // (bit0, bit1) = (e, 1-e)
@@ -896,14 +943,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
 #pragma unroll
                     for (int m2 = 0; m2 < 2; ++m2) acc[m2] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                        for (int m2 = 0; m2 < 2; ++m2) acc[m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[2 * half + m2][i], Dhi[i], acc[m2], 0, 0, 0);
-#pragma unroll
-                        for (int m2 = 0; m2 < 2; ++m2) acc[m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Whi[2 * half + m2][i], Dlo[i], acc[m2], 0, 0, 0);
-#pragma unroll
-                        for (int m2 = 0; m2 < 2; ++m2) acc[m2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wlo[2 * half + m2][i], Dhi[i], acc[m2], 0, 0, 0);
-                    }
+                    for (int i = 0; i < 2; ++i) mfma_planes_pair<NP>(W[2 * half][i], W[2 * half + 1][i], Dp[i], acc);
 #pragma unroll
                     for (int m2 = 0; m2 < 2; ++m2) {
                         const int mt = 2 * half + m2;
@@ -957,8 +997,9 @@ struct PackArgs {
     int in_dim;
     float* wih_perm;        // [2*4H][in_dim]
     float* bias_perm;       // [2*4H]
-    unsigned short* wpf;    // forward A-operand pack  [2][64 tiles][8 ks][2 hl][64 lanes][8]
-    unsigned short* wpb;    // backward A-operand pack [2][16 tiles][32 ks][2 hl][64 lanes][8]
+    unsigned short* wpf;    // forward A-operand pack  [2][64 tiles][8 ks][planes][64 lanes][8]
+    unsigned short* wpb;    // backward A-operand pack [2][16 tiles][32 ks][planes][64 lanes][8]
+    int planes;             // 2 (hi, lo) or 3 (hi, mid, lo)
 };
 
 __global__ __launch_bounds__(256) void lstm_pack_kernel(PackArgs p) {
@@ -982,10 +1023,13 @@ __global__ __launch_bounds__(256) void lstm_pack_kernel(PackArgs p) {
         {
             const int row = lane & 15, uu = row >> 2, gate = row & 3;
             const int k = 32 * ks + 8 * (lane >> 4) + j;
-            const float v = p.w_hh[dir][(size_t)(gate * HID + 4 * tau + uu) * HID + k];
-            unsigned short hi, lo; split_bf16(v, hi, lo);
-            const size_t base = ((((size_t)(dir * 64 + tau) * 8 + ks) * 2) * 64 + lane) * 8 + j;
-            p.wpf[base] = hi; p.wpf[base + 64 * 8] = lo;
+            float v = p.w_hh[dir][(size_t)(gate * HID + 4 * tau + uu) * HID + k];
+            const size_t base = ((((size_t)(dir * 64 + tau) * 8 + ks) * p.planes) * 64 + lane) * 8 + j;
+            for (int pl = 0; pl < p.planes; ++pl) {
+                const unsigned short b = f2bf(v);
+                p.wpf[base + (size_t)pl * 64 * 8] = b;
+                v -= bf2f(b);
+            }
         }
         // backward pack element: reinterpret the same flat index as [dir][mu][ks32][lane][j]
         j = (int)(i & 7); r = i >> 3;
@@ -996,10 +1040,13 @@ __global__ __launch_bounds__(256) void lstm_pack_kernel(PackArgs p) {
             const int ko = 16 * mu + (lane & 15);
             const int rp = 32 * ks32 + 8 * (lane >> 4) + j;   // r' = unit*4 + gate
             const int unit = rp >> 2, gate = rp & 3;
-            const float v = p.w_hh[dir][(size_t)(gate * HID + unit) * HID + ko];
-            unsigned short hi, lo; split_bf16(v, hi, lo);
-            const size_t base = ((((size_t)(dir * 16 + mu) * 32 + ks32) * 2) * 64 + lane) * 8 + j;
-            p.wpb[base] = hi; p.wpb[base + 64 * 8] = lo;
+            float v = p.w_hh[dir][(size_t)(gate * HID + unit) * HID + ko];
+            const size_t base = ((((size_t)(dir * 16 + mu) * 32 + ks32) * p.planes) * 64 + lane) * 8 + j;
+            for (int pl = 0; pl < p.planes; ++pl) {
+                const unsigned short b = f2bf(v);
+                p.wpb[base + (size_t)pl * 64 * 8] = b;
+                v -= bf2f(b);
+            }
         }
     }
 }
@@ -1053,7 +1100,8 @@ WsLayout lstm_ws_layout(int B, bool backward) {
     l.NBG = (B + 15) / 16;
     const int ncl = 2 * l.NBG;
     l.NCL8 = (ncl + 7) / 8 * 8;
-    const size_t slot = backward ? (size_t)16 * 16 * 256 * 4 : (size_t)32 * 16 * 2 * 16;
+    // forward: sized for three planes (24 KiB per parity); the two-plane kernel uses the first 2 x 16 KiB of a cluster's block
+    const size_t slot = backward ? (size_t)16 * 16 * 256 * 4 : (size_t)32 * 16 * 3 * 16;
     l.err = 0;                                   // 256 bytes
     l.hello = 256;                               // [clusters][16] words; err+hello zeroed every call
     l.progress = l.hello + pgasr_align_up((size_t)ncl * 16 * sizeof(unsigned), 256);   // one 128-B line per cluster
@@ -1071,23 +1119,25 @@ WsLayout lstm_ws_layout(int B, bool backward) {
 
 }  // namespace
 
-extern "C" size_t pgasr_lstm_pack_bytes(int which) {
-    // which: 0 = forward W_hh pack, 1 = backward W_hh pack (both 2 MB: bf16 hi+lo of 2 x 1024 x 256)
+extern "C" size_t pgasr_lstm_pack_bytes(int which, int planes) {
+    // which: 0 = forward W_hh pack, 1 = backward W_hh pack (both 1 MB per bf16 plane of 2 x 1024 x 256)
     (void)which;
-    return (size_t)2 * 64 * 8 * 2 * 64 * 8 * sizeof(unsigned short);
+    if (planes != 2 && planes != 3) return 0;
+    return (size_t)2 * 64 * 8 * planes * 64 * 8 * sizeof(unsigned short);
 }
 
 extern "C" int pgasr_lstm_pack_weights(const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f,
                                        const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
                                        int in_dim, float* wih_perm, float* bias_perm,
-                                       void* whh_pack_fwd, void* whh_pack_bwd, void* stream) {
+                                       void* whh_pack_fwd, void* whh_pack_bwd, int planes, void* stream) {
+    if (planes != 2 && planes != 3) return PGASR_ERR_INVALID_ARG;
     if (!w_ih_f || !w_hh_f || !b_ih_f || !b_hh_f || !w_ih_r || !w_hh_r || !b_ih_r || !b_hh_r) return PGASR_ERR_INVALID_ARG;
     if (!wih_perm || !bias_perm || !whh_pack_fwd || !whh_pack_bwd || in_dim <= 0) return PGASR_ERR_INVALID_ARG;
     PackArgs p;
     p.w_ih[0] = w_ih_f; p.w_hh[0] = w_hh_f; p.b_ih[0] = b_ih_f; p.b_hh[0] = b_hh_f;
     p.w_ih[1] = w_ih_r; p.w_hh[1] = w_hh_r; p.b_ih[1] = b_ih_r; p.b_hh[1] = b_hh_r;
     p.in_dim = in_dim; p.wih_perm = wih_perm; p.bias_perm = bias_perm;
-    p.wpf = (unsigned short*)whh_pack_fwd; p.wpb = (unsigned short*)whh_pack_bwd;
+    p.wpf = (unsigned short*)whh_pack_fwd; p.wpb = (unsigned short*)whh_pack_bwd; p.planes = planes;
     const size_t n_wih = (size_t)2 * 4 * HID * in_dim, n_pack = (size_t)2 * 64 * 8 * 64 * 8;
     const size_t n = n_wih > n_pack ? n_wih : n_pack;
     PGASR_LAUNCH_KERNEL(lstm_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
@@ -1169,8 +1219,15 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
         a.drop_k0 = (uint32_t)(drop_seed & 0xffffffffu); a.drop_k1 = (uint32_t)(drop_seed >> 32); a.drop_off = drop_offset;
     }
     dim3 grid((G_CLUSTER + a.n_helpers) * l.NCL8);   // + the helper workgroups of each cluster
-    if (backward) PGASR_LAUNCH_KERNEL(lstm_bwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
-    else PGASR_LAUNCH_KERNEL(lstm_fwd_kernel, grid, dim3(LSTM_THREADS), 0, st, a);
+    // flags bit 1: three bf16 planes per fp32 operand (the fp32-faithful sweeps); `wpack` must have been packed with planes = 3
+    const bool three = (flags & 2) != 0;
+    if (backward) {
+        if (three) PGASR_LAUNCH_KERNEL(lstm_bwd_kernel<3>, grid, dim3(LSTM_THREADS), 0, st, a);
+        else       PGASR_LAUNCH_KERNEL(lstm_bwd_kernel<2>, grid, dim3(LSTM_THREADS), 0, st, a);
+    } else {
+        if (three) PGASR_LAUNCH_KERNEL(lstm_fwd_kernel<3>, grid, dim3(LSTM_THREADS), 0, st, a);
+        else       PGASR_LAUNCH_KERNEL(lstm_fwd_kernel<2>, grid, dim3(LSTM_THREADS), 0, st, a);
+    }
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }

@@ -46,12 +46,24 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, unsigned long long n,
-                                                   float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
+                                                   float lr, float beta1, float beta2, float eps, int call,
                                                    float weight_decay, const int32_t* __restrict__ guard0,
-                                                   const int32_t* __restrict__ guard1) {
-    // guard words (the sticky error words of the step's sweep workspaces): a sweep that gave up on a bounded wait left
-    // invalid gradients behind -- the update is skipped, parameters and moments stay as they were (uniform branch)
-    if ((guard0 && *guard0 != 0) || (guard1 && *guard1 != 0)) return;
+                                                   const int32_t* __restrict__ guard1, int32_t* __restrict__ applied) {
+    // guard words (the sticky error words of the step's sweep workspaces, or the error flag that travelled through the
+    // gradient all-reduce): a sweep that gave up on a bounded wait -- on ANY rank -- left invalid gradients behind: the
+    // update is skipped, parameters and moments stay as they were (uniform branch)
+    const bool skip = (guard0 && *guard0 != 0) || (guard1 && *guard1 != 0);
+    // bias correction counts the updates that were APPLIED, not the calls: applied[(call-1)&1] = updates before this
+    // call, applied[call&1] := updates after it (ping-pong words: no block reads the word another block writes)
+    int eff = call;
+    if (applied) {
+        const int before = applied[(call - 1) & 1];
+        eff = before + 1;
+        if (blockIdx.x == 0 && threadIdx.x == 0) applied[call & 1] = skip ? before : eff;
+    }
+    if (skip) return;
+    const float bc1 = 1.f - powf(beta1, (float)eff);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)eff));
     // torch.optim.Adam semantics: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
     // p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
     const float step = lr / bc1;
@@ -135,17 +147,15 @@ extern "C" int pgasr_dropout(const float* x, float* y, unsigned long long n, flo
 
 extern "C" int pgasr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, unsigned long long n,
                                int step, float lr, float beta1, float beta2, float eps, float weight_decay,
-                               const int32_t* guard0, const int32_t* guard1, void* stream) {
+                               const int32_t* guard0, const int32_t* guard1, int32_t* applied, void* stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n == 0 || step < 1) return PGASR_ERR_INVALID_ARG;
     if ((((size_t)param) | ((size_t)grad) | ((size_t)exp_avg) | ((size_t)exp_avg_sq)) & 15) return PGASR_ERR_INVALID_ARG;
-    if ((((size_t)guard0) | ((size_t)guard1)) & 3) return PGASR_ERR_INVALID_ARG;
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    if ((((size_t)guard0) | ((size_t)guard1) | ((size_t)applied)) & 3) return PGASR_ERR_INVALID_ARG;
     unsigned blocks = (unsigned)((n / 4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
     PGASR_LAUNCH_KERNEL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
-                       lr, beta1, beta2, eps, bc1, bc2_sqrt, weight_decay, guard0, guard1);
+                       lr, beta1, beta2, eps, step, weight_decay, guard0, guard1, applied);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }

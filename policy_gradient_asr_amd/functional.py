@@ -36,11 +36,14 @@ class grad_overlap:
     def _key(cls):
         return torch.cuda.current_stream().cuda_stream
 
+    _main_of = {}      # side stream handle -> the main stream it serves
+
     @classmethod
     def side_stream(cls):
         k = cls._key()
         if k not in cls._sides:
             cls._sides[k] = streams.side_stream("weight_gradients")
+            cls._main_of[cls._sides[k].cuda_stream] = k
         return cls._sides[k]
 
     upper_grads_hook = None   # callable(swept_event): called by the FIRST layer's backward once every gradient above it is issued
@@ -56,6 +59,7 @@ class grad_overlap:
         return cls._sides2[k]
 
     _recent = {}       # the last event recorded on the main stream in the running backward pass (per main stream)
+    _feed_unjoined = {}   # main stream -> True while the feed stream carries work of this step that nothing has joined yet
 
     @classmethod
     def note_event(cls, ev):
@@ -110,6 +114,13 @@ class grad_overlap:
         cls._recent.pop(cls._key(), None)
         if cls._key() in cls._sides:
             torch.cuda.current_stream().wait_stream(cls.side_stream())
+        if cls._feed_unjoined.pop(cls._key(), False) and cls._key() in cls._sides2:
+            # ONE join of the feed stream per step, and only when the tail of backward has not made it already (the first
+            # layer's dW_hh runs on that stream and is joined through the weight-gradient stream): a fed forward sweep is
+            # not followed by a join of its own, which is safe only while the sweep really waits for every tile -- after a
+            # sweep time-out (survivable since round 2) or with overlap_weight_grads off the feed GEMMs could still be
+            # touching buffers that the next step's allocations reuse
+            torch.cuda.current_stream().wait_stream(cls.second_side_stream())
 
 
 class InstNormAffineFn(torch.autograd.Function):
@@ -286,7 +297,7 @@ class BLSTMLayerFn(torch.autograd.Function):
                 done = torch.zeros(need_words, dtype=torch.int32, device=x.device)
             zeroed = torch.cuda.Event()
             zeroed.record()
-            hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, fed=done, fed_need=G // 256, **dkw)
+            hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, fed=done, fed_need=hipops.x3w_feed_col_tiles(G), **dkw)
             side.wait_event(zeroed)
             busy = hipops.lstm_busy_ptr(T, B, False, x.device)
             with torch.cuda.stream(side):
@@ -294,6 +305,7 @@ class BLSTMLayerFn(torch.autograd.Function):
                 hipops.gemm_x3w_feed(x, prepacked.planes, gates, T * B, G, I, bias_perm, busy, done)
             for t_ in (x, gates, done, bias_perm) + tuple(prepacked.planes):
                 streams.hold(t_, side)
+            grad_overlap._feed_unjoined[main.cuda_stream] = True
             # no join: the sweep cannot end before every row tile it waited for is complete, so the stream that ran the sweep
             # is already behind the feed's stores; what is left of the GEMM then (workgroups finding the tile counter
             # exhausted) touches no operand.  The next fed sweep's GEMM is ordered on the feed stream itself.
@@ -375,10 +387,17 @@ class BLSTMLayerFn(torch.autograd.Function):
                 side_ = torch.cuda.current_stream()
                 for t_ in (dg, dx, done) + tuple(planes_t):
                     streams.hold(t_, side_)
-            grad_overlap._deferred[dx.data_ptr()] = {"dx": dx, "done": done, "need": I // 256, "drop": None, "launch": launch}
+            grad_overlap._deferred[dx.data_ptr()] = {"dx": dx, "done": done, "need": hipops.x3w_feed_col_tiles(I), "drop": None, "launch": launch}
         elif ctx.needs_input_grad[0]:
             dx = torch.empty(T, B, I, dtype=torch.float32, device=dev)
-            if ctx.planes_t is not None and hipops.gemm_x3w_ok(T * B, I, G):
+            if (ctx.sweep_follows and not ctx.has_dact and ctx.planes_t is not None and hipops.gemm_x3w_ok(T * B, I, G)
+                    and I == 2 * HID and hipops.x3w_feed_col_tiles(I) > 0 and T * B * I * 4 < 2 ** 31):
+                # the product that feed-ahead would have run beside the next sweep, in the sequential order: the SAME kernel
+                # with the same decomposition (its first tiles are fixed-order sums of K-quarters), no XCD mask, before the
+                # sweep -- so that both orders give the same bits
+                done = torch.zeros(2 * ((T * B + 255) // 256), dtype=torch.int32, device=dev)
+                hipops.gemm_x3w_feed(dg, ctx.planes_t, dx, T * B, I, G, None, 0, done, order=1)
+            elif ctx.planes_t is not None and hipops.gemm_x3w_ok(T * B, I, G):
                 hipops.gemm_x3w(dg, ctx.planes_t, dx, T * B, I, G,
                                 dact_y=dact_y if ctx.has_dact else None, slope=LEAKY_SLOPE)
             else:
@@ -412,6 +431,8 @@ class BLSTMLayerFn(torch.autograd.Function):
             hipops.colsum(dbias_part, dbias_part.shape[0], G, G, dbias)      # the sweep summed dgates over t per group
             if hh_stream is not None:
                 cur.wait_stream(hh_stream)
+                if hh_stream is grad_overlap._sides2.get(grad_overlap._main_of.get(cur.cuda_stream)):
+                    grad_overlap._feed_unjoined.pop(grad_overlap._main_of[cur.cuda_stream], None)   # joined through this stream
             else:
                 dwhh = hh()
             if accumulate_into is not None:
@@ -456,7 +477,9 @@ def prepack_blstm(params, in_dim):
     params = [p.contiguous() for p in params]
     pk.wih_perm, pk.bias_perm, pk.pack_f, pk.pack_b = hipops.lstm_pack(params, in_dim)
     G = 2 * 4 * HID
-    ok = in_dim % 32 == 0 and in_dim % 128 == 0          # both GEMM roles of W_ih: N=G,K=in and N=in,K=G
+    # both GEMM roles of W_ih: N=G,K=in and N=in,K=G; the pre-split planes (and with them the LDS-DMA GEMM and the
+    # feed-ahead order) belong to the bf16x3 mode -- in "f32" mode the projections run on the exact fp32 MFMA kernel
+    ok = in_dim % 32 == 0 and in_dim % 128 == 0 and hipops.GEMM_PRECISION == 1
     pk.planes = hipops.split_planes(pk.wih_perm) if ok else None                      # (G, in): forward projection
     pk.planes_t = hipops.split_planes(pk.wih_perm, transpose=True) if ok else None    # (in, G): input gradient
     pk.ready = None

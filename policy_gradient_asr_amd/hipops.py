@@ -285,6 +285,45 @@ def reinforce_grad(scores, path, coef, lengths, out=None, accumulate=False):
 # ------------------------------------------------------------------------------------------
 GEMM_XCC_BUSY_PTR = 0   # device address of a sweep's 8 busy counters (0 = plain launch); set around side-stream GEMMs
 GEMM_PRECISION = 1   # default for the model's GEMMs: 1 = bf16x3 split MFMA, 0 = exact fp32 MFMA
+LSTM_PLANES = 2      # bf16 planes per fp32 operand in the recurrent sweeps: 2 = hi/lo, 3 products (default); 3 = hi/mid/lo, 6 products
+
+# The arithmetic of the whole path is a MODE of the host layer:
+#   "bf16x3": every dense product = 3 bf16 MFMA terms of a 2-plane split (~16 operand bits), fp32 accumulate; the input
+#             affine (whose sign feeds leaky_relu') on the exact fp32 MFMA.  Within north_star's 1e-3 bar; the fast path.
+#   "f32":    the reference's arithmetic (torch fp32: nn.Linear / nn.LSTM, model.py:38-44): every hoisted GEMM on the exact
+#             fp32 MFMA (v_mfma_f32_32x32x2_f32), the recurrent sweeps on the 3-plane split with six products (every term
+#             down to 2^-24).  No pre-split bf16 weight planes exist in this mode, so the LDS-DMA GEMM and the feed-ahead
+#             order (both bf16x3 kernels) are not used: projections run before their sweeps.
+PRECISION_MODES = {"bf16x3": (1, 2), "f32": (0, 3)}
+_precision = "bf16x3"
+
+
+def set_precision(mode):
+    global GEMM_PRECISION, LSTM_PLANES, _precision
+    if mode not in PRECISION_MODES:
+        raise ValueError(f"precision mode must be one of {sorted(PRECISION_MODES)}")
+    GEMM_PRECISION, LSTM_PLANES = PRECISION_MODES[mode]
+    _precision = mode
+
+
+def get_precision():
+    return _precision
+
+
+class precision:
+    """``with hipops.precision("f32"): ...`` -- the mode for everything launched inside."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = _precision
+        set_precision(self.mode)
+        return self
+
+    def __exit__(self, *a):
+        set_precision(self.prev)
+        return False
 
 
 def gemm(A, B, C, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=None, alpha=1.0,
@@ -396,13 +435,19 @@ def lstm_pack(params, in_dim):
         _req(t, torch.float32, "lstm parameter")
     wih_perm = torch.empty(2 * 4 * HID, in_dim, dtype=torch.float32, device=dev)
     bias_perm = torch.empty(2 * 4 * HID, dtype=torch.float32, device=dev)
-    nb = lib.pgasr_lstm_pack_bytes(0)
+    nb = lib.pgasr_lstm_pack_bytes(0, LSTM_PLANES)
     pack_f = torch.empty(nb, dtype=torch.uint8, device=dev)
     pack_b = torch.empty(nb, dtype=torch.uint8, device=dev)
     st = lib.pgasr_lstm_pack_weights(*[_p(t) for t in params], in_dim, _p(wih_perm), _p(bias_perm),
-                                     _p(pack_f), _p(pack_b), _stream())
+                                     _p(pack_f), _p(pack_b), LSTM_PLANES, _stream())
     _lib.check(st, "pgasr_lstm_pack_weights")
     return wih_perm, bias_perm, pack_f, pack_b
+
+
+def _lstm_flags(pack):
+    """Sweep flags for a W_hh pack made by ``lstm_pack``: the pack's size says how many planes it holds."""
+    planes = 3 if pack.numel() == _lib.load().pgasr_lstm_pack_bytes(0, 3) else 2
+    return LSTM_FLAGS | (2 if planes == 3 else 0)
 
 
 def lstm_unpack_grads(dwih_perm, dbias_perm, dwhh_perm, in_dim, grads, accumulate=False):
@@ -439,12 +484,12 @@ def lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, fed=None, fed_need=0
     dargs = (_p(out_drop), float(p), int(seed) & (2 ** 64 - 1), int(offset) & 0xFFFFFFFF)
     with _timed("lstm_fwd_kernel"):
         if fed is None:
-            st = lib.pgasr_lstm_layer_fwd(_p(gates), _p(out), _p(cbuf), _p(pack_f), _p(lengths), T, B, LSTM_FLAGS, *dargs,
+            st = lib.pgasr_lstm_layer_fwd(_p(gates), _p(out), _p(cbuf), _p(pack_f), _p(lengths), T, B, _lstm_flags(pack_f), *dargs,
                                           _p(ws), ws.numel(), _stream())
         else:
             if fed.dtype != torch.int32 or not fed.is_cuda or fed.numel() < 2 * ((T * B + 255) // 256):
                 raise _lib.PgasrError("lstm_layer_fwd: fed must be an int32 GPU tensor of 2 * ceil(T*B/256) words")
-            st = lib.pgasr_lstm_layer_fwd_fed(_p(gates), _p(out), _p(cbuf), _p(pack_f), _p(lengths), T, B, LSTM_FLAGS,
+            st = lib.pgasr_lstm_layer_fwd_fed(_p(gates), _p(out), _p(cbuf), _p(pack_f), _p(lengths), T, B, _lstm_flags(pack_f),
                                               _p(fed), int(fed_need), *dargs, _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_lstm_layer_fwd_fed" if fed is not None else "pgasr_lstm_layer_fwd")
     return ws
@@ -453,6 +498,12 @@ def lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, fed=None, fed_need=0
 def lstm_fed_ok(T, B):
     """Can a forward sweep of this shape be fed by a concurrent projection GEMM (B <= 32, helpers on)?"""
     return bool(_lib.load().pgasr_lstm_fed_ok(T, B, LSTM_FLAGS))
+
+
+def x3w_feed_col_tiles(N):
+    """Column tiles per direction half that ``gemm_x3w_feed`` counts per row tile for an N-column product: the
+    ``fed_need`` of the sweep it feeds (0: not a feedable width)."""
+    return int(_lib.load().pgasr_gemm_x3w_feed_col_tiles(int(N)))
 
 
 def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done, order=0):
@@ -483,13 +534,13 @@ def lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=Fal
     part = torch.empty((B + 15) // 16, 2 * 4 * HID, dtype=torch.float32, device=gates.device) if want_dbias else None
     with _timed("lstm_bwd_kernel"):
         if fed is None:
-            st = lib.pgasr_lstm_layer_bwd(_p(gates), _p(out), _p(cbuf), _p(dout), _p(pack_b), _p(lengths), T, B, LSTM_FLAGS,
+            st = lib.pgasr_lstm_layer_bwd(_p(gates), _p(out), _p(cbuf), _p(dout), _p(pack_b), _p(lengths), T, B, _lstm_flags(pack_b),
                                           _p(part), _p(ws), ws.numel(), _stream())
         else:
             if fed.dtype != torch.int32 or not fed.is_cuda or fed.numel() < 2 * ((T * B + 255) // 256):
                 raise _lib.PgasrError("lstm_layer_bwd: fed must be an int32 GPU tensor of 2 * ceil(T*B/256) words")
             p, seed, offset = drop if drop is not None else (0.0, 0, 0)
-            st = lib.pgasr_lstm_layer_bwd_fed(_p(gates), _p(out), _p(cbuf), _p(dout), _p(pack_b), _p(lengths), T, B, LSTM_FLAGS,
+            st = lib.pgasr_lstm_layer_bwd_fed(_p(gates), _p(out), _p(cbuf), _p(dout), _p(pack_b), _p(lengths), T, B, _lstm_flags(pack_b),
                                               _p(part), _p(fed), int(fed_need), float(p), int(seed), int(offset),
                                               _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_lstm_layer_bwd")
@@ -528,8 +579,13 @@ def lstm_assert_no_timeouts():
 def lstm_error_words(device):
     """Device addresses of the sticky error words of the sweep workspaces used on the CURRENT stream (at most two:
     forward, backward) -- the guards of ``adam_step``."""
+    return [w.data_ptr() for w in lstm_error_word_tensors(device)]
+
+
+def lstm_error_word_tensors(device):
+    """The same words as int32 (1,) views (their workspaces start with the error word)."""
     cur = torch.cuda.current_stream().cuda_stream
-    return [ws.data_ptr() for key, ws in _ws_cache.items()
+    return [ws[:4].view(torch.int32) for key, ws in _ws_cache.items()
             if key[0].startswith("lstm") and key[1] == device and key[2] == cur][:2]
 
 
@@ -599,15 +655,22 @@ def stream_copy(dst, src, workgroups=8):
     return dst
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, guards=()):
-    """guards: up to two device addresses of int32 words (``lstm_error_words``); the update is skipped while one is set."""
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, guards=(),
+              applied=None):
+    """guards: up to two device addresses of int32 words (``lstm_error_words``, or the word of the gradient buffer that
+    carried the error flag through the all-reduce); the update is skipped while one is set.
+    applied: int32 (2,) GPU tensor, zeroed once: the count of updates really applied lives there (bias correction then
+    ignores skipped calls); ``step`` stays the 1-based count of calls."""
     lib = _lib.load()
     for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         _req(t, torch.float32, nm)
+    _req(applied, torch.int32, "applied")
+    if applied is not None and applied.numel() != 2:
+        raise _lib.PgasrError("adam_step: applied must hold two int32 words")
     g = list(guards)[:2] + [0, 0]
     _lib.check(lib.pgasr_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), int(step),
                                    float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
-                                   g[0], g[1], _stream()), "pgasr_adam_step")
+                                   g[0], g[1], _p(applied), _stream()), "pgasr_adam_step")
 
 
 def lstm_busy_ptr(T, B, backward, device, stream=None):

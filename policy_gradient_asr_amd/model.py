@@ -183,7 +183,10 @@ def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset
     if resume and os.path.exists(ckpt):
         st = torch.load(ckpt, map_location=dev)
         model.load_state_dict(st["model"])
-        trainer.exp_avg.copy_(st["exp_avg"]); trainer.exp_avg_sq.copy_(st["exp_avg_sq"]); trainer.nstep = st["nstep"]
+        from .train_step import FLAG_PAD
+        # the checkpoint holds the moments of the PARAMETERS (the flat buffers' leading flag words are not state)
+        trainer.exp_avg[FLAG_PAD:].copy_(st["exp_avg"]); trainer.exp_avg_sq[FLAG_PAD:].copy_(st["exp_avg_sq"]); trainer.nstep = st["nstep"]
+        trainer.set_applied_steps(st.get("applied_steps", st["nstep"]))     # Adam's bias correction counts applied updates
         # the dropout masks are functions of (seed, call counter): restore both, or a resumed run replays the first
         # epoch's masks and differs from an uninterrupted one
         model.encoder._drop_calls = st.get("drop_calls", 0)
@@ -239,7 +242,9 @@ def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset
             torch.save(sd, os.path.join(model_path, "model_best.pth"))
             best = curr
         torch.save(sd, os.path.join(model_path, "model_last.pth"))
-        torch.save({"model": sd, "exp_avg": trainer.exp_avg, "exp_avg_sq": trainer.exp_avg_sq, "nstep": trainer.nstep,
+        from .train_step import FLAG_PAD
+        torch.save({"model": sd, "exp_avg": trainer.exp_avg[FLAG_PAD:], "exp_avg_sq": trainer.exp_avg_sq[FLAG_PAD:], "nstep": trainer.nstep,
+                    "applied_steps": trainer.applied_steps(),
                     "losses": losses, "val_losses": val_losses, "best": best, "epoch": epoch,
                     "drop_calls": model.encoder._drop_calls, "dropout_seed": model.encoder.dropout_seed,
                     "lr": lr, "lam": lam}, ckpt)

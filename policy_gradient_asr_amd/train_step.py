@@ -8,19 +8,28 @@ decode, reward and REINFORCE gradient, so the gradient all-reduce is the only co
 is normalised by the GLOBAL batch so 1-GPU and N-GPU gradients agree to fp32 rounding.
 """
 import os
+import threading
 
 import torch
 import torch.distributed as dist
 
+# Leading fp32 words of both flat buffers (256 bytes: the parameters keep their alignment).  Word 0 of the GRADIENT
+# buffer carries the step's error flag through the gradient all-reduce: every rank writes 1.0 there when one of its
+# sweeps timed out, the SUM is > 0 on every rank, and the guarded Adam of every rank reads that word -- all replicas skip
+# the update or none does (the rank-local guard let replicas diverge, and let the other ranks apply a reduced gradient
+# that contained the failed rank's garbage).
+FLAG_PAD = 64
+_step_lock = threading.Lock()     # the host layer keeps per-process state (grad_overlap, held tensors): one step at a time
 
-def flatten_parameters(model):
-    """Re-point every parameter (and its .grad) at a slice of one flat buffer."""
+
+def flatten_parameters(model, pad=0):
+    """Re-point every parameter (and its .grad) at a slice of one flat buffer (``pad`` leading words stay free)."""
     params = [p for p in model.parameters()]
     dev = params[0].device
-    total = sum(p.numel() for p in params)
-    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    total = pad + sum(p.numel() for p in params)
+    flat = torch.zeros(total, dtype=torch.float32, device=dev)
     gflat = torch.zeros(total, dtype=torch.float32, device=dev)
-    off = 0
+    off = pad
     with torch.no_grad():
         for p in params:
             n = p.numel()
@@ -63,11 +72,19 @@ class DataParallelStep:
     Subclasses provide ``forward_loss(batch, global_batch) -> scalar loss`` already divided by the
     GLOBAL batch size, so the summed gradient is the global-batch gradient."""
 
-    def __init__(self, model, lr=5e-4, world_size=1, process_group=None):
+    def __init__(self, model, lr=5e-4, world_size=1, process_group=None, precision=None):
+        """precision: "bf16x3" (default: 3-term bf16 split MFMA products, within the 1e-3 bar) or "f32" (the reference's
+        arithmetic, torch fp32: exact fp32 MFMA GEMMs + 3-plane / 6-product recurrent sweeps) -- hipops.PRECISION_MODES;
+        None = whatever mode is set when a step runs."""
+        if precision is not None:
+            from . import hipops
+            if precision not in hipops.PRECISION_MODES:
+                raise ValueError(f"precision must be one of {sorted(hipops.PRECISION_MODES)} or None")
+        self.precision = precision
         self.model = model
         self.world = world_size
         self.pg = process_group
-        self.flat, self.gflat = flatten_parameters(model)
+        self.flat, self.gflat = flatten_parameters(model, FLAG_PAD)
         self.flat_param = torch.nn.Parameter(self.flat)
         self.flat_param.grad = self.gflat
         # Adam(lr=5e-4) is the reference's commented choice (model.py:207)
@@ -75,10 +92,12 @@ class DataParallelStep:
         if self.flat.is_cuda:
             self.exp_avg = torch.zeros_like(self.flat)
             self.exp_avg_sq = torch.zeros_like(self.flat)
+            self.applied = torch.zeros(2, dtype=torch.int32, device=self.flat.device)   # updates really applied (pgasr_adam_step)
             self.opt = None
         else:   # CPU is only the gloo plumbing test: torch's Adam
             self.opt = torch.optim.Adam([self.flat_param], lr=lr)
-        self.nstep = 0
+            self.applied_cpu = 0
+        self.nstep = 0                      # CALLS of step() (seeds the sampler / dropout offsets); see applied_steps()
         self.collective = self.world > 1    # tests set this on a 1-rank group to exercise the plumbing
         self._early = None                  # (split, work) of an all-reduce issued during backward
         if self.world > 1:
@@ -86,7 +105,7 @@ class DataParallelStep:
 
     def param_offset(self, name):
         """Offset in the flat buffers of the parameter called ``name`` (model.named_parameters() order)."""
-        off = 0
+        off = FLAG_PAD
         for n, p in self.model.named_parameters():
             if n == name:
                 return off
@@ -123,6 +142,33 @@ class DataParallelStep:
     def forward_loss(self, batch, global_batch):  # pragma: no cover - abstract
         raise NotImplementedError
 
+    def local_error_flag(self):
+        """0-d / 1-element fp32 tensor on the gradients' device: > 0 iff THIS rank's step produced invalid gradients (a
+        persistent sweep gave up on a bounded wait; the words are sticky).  None: nothing to report (CPU plumbing)."""
+        if not self.flat.is_cuda:
+            return None
+        from . import hipops
+        words = hipops.lstm_error_word_tensors(self.flat.device)
+        if not words:
+            return None
+        flag = words[0].ne(0)
+        for w in words[1:]:
+            flag = flag | w.ne(0)
+        return flag.to(torch.float32)
+
+    def applied_steps(self):
+        """Number of Adam updates really applied (synchronises): ``nstep`` minus the updates the guard skipped."""
+        if self.opt is not None:
+            return self.applied_cpu
+        return int(self.applied[self.nstep & 1].item())
+
+    def set_applied_steps(self, n):
+        """Checkpoint resume: the bias correction continues from ``n`` applied updates."""
+        if self.opt is not None:
+            self.applied_cpu = int(n)
+        else:
+            self.applied.fill_(int(n))
+
     def backward(self, loss):
         loss.backward()
 
@@ -130,24 +176,45 @@ class DataParallelStep:
         from . import streams
         # every side stream of the step is joined into the calling stream by the time backward() returns, so tensors that
         # cross streams are kept alive until the next step begins instead of being handed to record_stream (streams.hold)
-        with streams.managed_step():
-            return self._step(*batch)
+        if not _step_lock.acquire(blocking=False):
+            raise RuntimeError("policy_gradient_asr_amd: one train step at a time per process (the host layer's overlap / "
+                               "stream state is process-global); a second trainer may only step between the steps of the first")
+        try:
+            with streams.managed_step():
+                if self.precision is not None and self.flat.is_cuda:
+                    from . import hipops
+                    with hipops.precision(self.precision):
+                        return self._step(*batch)
+                return self._step(*batch)
+        finally:
+            _step_lock.release()
 
     def _step(self, *batch):
         local_b = batch[0].shape[0]
         self.gflat.zero_()
         loss = self.forward_loss(batch, local_b * self.world)
         self.backward(loss)
+        if self.collective:
+            # the error flag travels with the last gradient bucket (word 0, see FLAG_PAD): SUM > 0 on every rank iff any
+            # rank's gradients are invalid
+            flag = self.local_error_flag()
+            if flag is not None:
+                self.gflat[0:1].copy_(flag.reshape(1))
         self.reduce_rest()
         self.nstep += 1
         if self.opt is None:
             from . import hipops
             # a sweep that timed out in this step (or an earlier one: the words are sticky) left invalid gradients:
-            # the update is skipped on the device; the host raises at its next check (hipops.lstm_assert_no_timeouts)
+            # the update is skipped on the device -- on every rank, since the guard is the reduced flag -- and does not
+            # count for the bias correction; the host raises at its next check (hipops.lstm_assert_no_timeouts)
+            guards = [self.gflat.data_ptr()] if self.collective else hipops.lstm_error_words(self.flat.device)
             hipops.adam_step(self.flat, self.gflat, self.exp_avg, self.exp_avg_sq, self.nstep, lr=self.lr,
-                             guards=hipops.lstm_error_words(self.flat.device))
+                             guards=guards, applied=self.applied)
+        elif self.collective and float(self.gflat[0]) > 0:
+            pass                                # CPU plumbing (gloo tests): same rule, checked on the host
         else:
             self.opt.step()
+            self.applied_cpu += 1
         return loss.detach()
 
 
@@ -157,11 +224,11 @@ class PolicyGradientTrainer(DataParallelStep):
     Returns the detached local loss (no host sync)."""
 
     def __init__(self, model, lr=5e-4, lam=1.0, seed=0, blank=0, world_size=1, process_group=None, rank=0,
-                 reward_decoder="greedy", beam_size=16):
+                 reward_decoder="greedy", beam_size=16, precision=None):
         """reward_decoder: which hypothesis the self-critical baseline reward comes from -- "greedy" (best path) or
         "beam": the reference's own reward definition (policy_grad.py:6-8: prefix beam search -> collapse_fn ->
         edit distance), decoded on the device with ``beam_size`` (BASELINE config 5: 16; the reference passes 5)."""
-        super().__init__(model, lr=lr, world_size=world_size, process_group=process_group)
+        super().__init__(model, lr=lr, world_size=world_size, process_group=process_group, precision=precision)
         if reward_decoder not in ("greedy", "beam"):
             raise ValueError("reward_decoder must be 'greedy' or 'beam'")
         self.reward_decoder, self.beam_size = reward_decoder, int(beam_size)
@@ -180,6 +247,23 @@ class PolicyGradientTrainer(DataParallelStep):
             self.upper_split = self.param_offset("encoder.blstm.weight_ih_l1")
         except KeyError:
             self.upper_split = None
+
+    MAX_LOCAL_BATCH = 128      # pgasr_lstm_layer_fwd/bwd: at most 16 clusters of 16 utterances are co-resident
+    MAX_VOCAB = 64             # CTC lattice / frame kernels: one wave per (t, b) row
+
+    def _check_limits(self, x, targets):
+        """The kernels' compiled-in limits, stated where the caller can read them (otherwise the first symptom is a
+        PGASR_ERR_UNSUPPORTED from deep inside the step)."""
+        if x.dim() != 3 or targets.dim() != 2:
+            raise ValueError("step(x, targets, fmask, tmask): x (B,F,T), targets (B,L)")
+        if x.shape[0] > self.MAX_LOCAL_BATCH:
+            raise ValueError(f"local batch {x.shape[0]} > {self.MAX_LOCAL_BATCH}: the persistent LSTM sweeps keep at most 16 "
+                             "clusters of 16 utterances resident on the chip; use more ranks or smaller batches")
+        vocab = getattr(getattr(self.model, "head", None), "out_features", None)
+        if vocab is not None and vocab > self.MAX_VOCAB:
+            raise ValueError(f"alphabet of {vocab} symbols > {self.MAX_VOCAB}: the CTC / sampling kernels hold one frame's scores in one wave")
+        if self.reward_decoder == "beam" and self.beam_size > 128:
+            raise ValueError("beam_size > 128 is not supported by pgasr_ctc_beam_search")
 
     def staging_stream(self):
         """The stream on which the NEXT batch is to be staged into HBM once ``step()`` has returned (model.py:227-230's
@@ -215,14 +299,14 @@ class PolicyGradientTrainer(DataParallelStep):
         grad_overlap.upper_grads_hook = self._upper_grads_issued if early else None
         if self._one is None or self._one.device != loss.device:
             self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
-        PGCTCLossFn.unit_grad = True            # the seed gradient below IS 1: no fill, no 3.7 MB multiply on the chain
+        PGCTCLossFn.unit_seed_ptr = self._one.data_ptr()   # the seed gradient below IS 1: no fill, no 3.7 MB multiply on the chain
         try:
             loss.backward(gradient=self._one)
         except BaseException:
             grad_overlap._deferred.clear()      # do not let finish() mask the error with its own complaint
             raise
         finally:
-            PGCTCLossFn.unit_grad = False
+            PGCTCLossFn.unit_seed_ptr = None
             grad_overlap.enabled = False
             grad_overlap.upper_grads_hook = None
             grad_overlap.finish()
@@ -231,6 +315,7 @@ class PolicyGradientTrainer(DataParallelStep):
         from .loss import pg_ctc_loss
         x, targets, fmask, tmask = batch
         from . import hipops
+        self._check_limits(x, targets)
         if (fmask.dtype == torch.float32 and tmask.dtype == torch.int64 and targets.dtype == torch.int64 and targets.dim() == 2
                 and targets.shape[1] > 0 and fmask.is_contiguous() and tmask.is_contiguous() and targets.is_contiguous()):
             in_len, tg_len, tg = hipops.batch_prep(fmask, tmask, targets)       # the collate_custom dtypes: one launch

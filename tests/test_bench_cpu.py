@@ -21,6 +21,26 @@ def test_launcher_exits_nonzero_without_enough_gpus():
     assert r.returncode == 2 and "GPU(s) are visible" in r.stderr
 
 
+def test_gpu_count_comes_from_sysfs_not_from_hip(tmp_path, monkeypatch):
+    """The parent of a multi-rank run counts GPUs in the KFD topology (simd_count > 0) and applies the *_VISIBLE_DEVICES
+    lists; without sysfs it leaves the check to the ranks.  bench.launch_ranks never calls torch.cuda."""
+    import inspect
+    assert "torch.cuda" not in inspect.getsource(bench.launch_ranks) and "torch.cuda" not in inspect.getsource(bench.visible_gpu_count)
+    nodes = tmp_path / "nodes"
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text(f"cpu_cores_count 0\nsimd_count {simd}\nmem_banks_count 1\n")
+    real_listdir, real_open = os.listdir, open
+    monkeypatch.setattr(bench.os, "listdir", lambda p: real_listdir(str(nodes)) if "kfd" in p else real_listdir(p))
+    import builtins
+    monkeypatch.setattr(builtins, "open", lambda p, *a, **k: real_open(str(p).replace("/sys/class/kfd/kfd/topology/nodes", str(nodes)), *a, **k))
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpu_count() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpu_count() == 2
+
+
 def test_world_size_mismatch_is_an_error():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
@@ -47,3 +67,14 @@ def test_bucketed_pool_balances_ranks():
         # length bucketing: a batch's utterances are of similar length (half the corpus range at most)
         alln = [n for r in range(world) for n in pools[r][step]]
         assert max(alln) - min(alln) <= (bench.T // 2) // 2 + 8
+
+
+def test_roofline_record_counts_launches_per_sampled_step():
+    """launches_per_step is launches / SAMPLED steps (only every n-th timed step carries HIP events), 3 per
+    step for a three-layer model, and the achieved rate follows from the average launch time."""
+    prof = {"lstm_fwd_kernel": (5 * 3 * 1.10, 15), "lstm_bwd_kernel": (5 * 3 * 1.30, 15), "gemm_f32": (9.0, 100)}
+    rl = bench.sweep_roofline(prof, n_sampled=5, frames_per_step=bench.B_PER_GPU * bench.T)
+    assert rl["kernel"] == "lstm_bwd_kernel" and rl["launches_per_step"] == 3
+    assert abs(rl["avg_launch_ms"] - 1.30) < 1e-12
+    assert abs(rl["flops_per_launch"] - 2 * 2 * 32 * 256 * 1024 * 1000) < 1
+    assert abs(rl["achieved"] - rl["flops_per_launch"] / 1.30e-3 / 1e12) < 1e-9 and abs(rl["peak"] - 2500 / 3) < 1e-9

@@ -90,6 +90,26 @@ def test_small_beam_kernel_vs_oracle_and_generic(T, B, V, beam, blank):
         assert int(ctok[b, ctl[b]:].abs().sum()) == 0
 
 
+def test_long_utterance_small_beam_goes_to_the_generic_kernel():
+    """the single-wave kernel stages a hypothesis in 8 KB of LDS (4096 tokens); T * beam <= 24576 alone would
+    admit T = 4500 at beam 1 (the reference's own beam is 5: T up to 4915).  Such inputs must take the generic kernel:
+    hypothesis and score equal the fp64 oracle's, and a hypothesis longer than 4096 tokens comes out whole."""
+    from policy_gradient_asr_amd import hipops
+    T, V = 4500, 5
+    rng = np.random.default_rng(7)
+    logits = rng.normal(size=(T, 2, V)) * 4.0
+    logits[:, 1, :] = -20.0
+    logits[np.arange(T), 1, 1 + (np.arange(T) % 2)] = 20.0        # utterance 1 alternates symbols 1, 2: 4500 tokens
+    lp = torch.log_softmax(torch.tensor(logits, dtype=torch.float32), 2).to(DEV)
+    for beam in (1, 5):
+        tok, tl, score = hipops.ctc_beam_search(lp, None, beam=beam)
+        gtok, gtl, gscore = hipops.ctc_beam_search(lp, None, beam=beam, generic=True)
+        assert torch.equal(tok, gtok) and torch.equal(tl, gtl) and torch.equal(score, gscore)
+        assert int(tl[1]) == T and list(tok[1, :6].cpu().numpy()) == [1, 2, 1, 2, 1, 2]
+        want, nll = decode_ref.prefix_beam_search(np.exp(lp[:, 0].double().cpu().numpy()), beam_size=beam)
+        assert list(tok[0, :tl[0]].cpu().numpy()) == list(want) and float(score[0]) == pytest.approx(nll, rel=1e-6)
+
+
 def test_beam_headline_size_properties():
     """T=1000,B=32,beam=16: runs, scores finite and never better than the CTC total."""
     from policy_gradient_asr_amd import hipops

@@ -46,6 +46,11 @@ def test_gemm_layouts(tA, tB, M, N, K, precision, tol):
     (1000, 256, 96, True, True),        # 3 k-tiles (one per stage), ragged last row tile, both epilogues
     (513, 384, 160, False, True),       # 5 k-tiles: the 3-stage ring wraps
     (4096, 512, 2048, False, False),    # dX shape of the path (K = 8H)
+    # N % 256 == 0: the 256 x 256 tile (one 16-deep k-step per stage, four stages, k-steps in pairs)
+    (300, 256, 32, True, True),         # two k-steps: fewer than the ring's four stages
+    (777, 768, 64, True, False),        # four k-steps = one turn of the ring; ragged last row tile; three column tiles
+    (2000, 2048, 512, False, True),     # the input projection's K and N
+    (1031, 512, 352, True, True),       # 22 k-steps: the ring wraps five times, odd number of pairs
 ])
 def test_gemm_x3w_lds_dma(M, N, K, with_bias, with_dact):
     """pgasr_gemm_x3w_f32 (LDS-DMA tiles, pre-split weight planes) against fp64, and against the
@@ -172,6 +177,51 @@ def test_blstm_layer_vs_torch_cpu(T, B, lens):
     assert rel_err(xg.grad.cpu(), xr.grad) < 1e-3
     for n, p in zip(names, params):
         assert rel_err(p.grad.cpu(), getattr(lstm, n).grad) < 1e-3, n
+
+
+LSTM_NAMES = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0",
+              "weight_ih_l0_reverse", "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+
+
+@pytest.mark.parametrize("T,B,lens", [
+    (40, 4, [40, 33, 1, 17]), (30, 19, list(range(30, 11, -1))), (200, 32, [200] * 32),
+    (5, 80, [5] * 50 + [2] * 30),                   # ten clusters: no helper workgroups
+    (1000, 16, [1000] * 8 + list(range(993, 500, -64))),     # the headline's chain length
+])
+def test_blstm_layer_f32_mode_vs_torch_cpu(T, B, lens):
+    """precision mode "f32" -- the reference's arithmetic (nn.LSTM in torch fp32, model.py:39-44): exact fp32 MFMA for
+    the hoisted products, 3-plane / 6-product sweeps.  Outputs and every gradient within 1e-5 (max norm) of torch-CPU
+    run in fp64 on the same fp32 parameters, i.e. at the level of torch's own fp32 rounding; the default bf16x3 mode is
+    measured beside it on the same case and must be the less exact of the two."""
+    from policy_gradient_asr_amd import functional as Fh, hipops
+    from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    lstm, x, dy, lengths = _lstm_case(T, B, lens, seed=T + B + 1)
+    l64 = torch.nn.LSTM(512, 256, 1, bidirectional=True).double()
+    l64.load_state_dict({k: v.double() for k, v in lstm.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    out, _ = l64(pack_padded_sequence(xr, lengths, enforce_sorted=False))
+    out, _ = pad_packed_sequence(out, total_length=T)
+    out.backward(dy.double())
+    errs = {}
+    for mode in ("f32", "bf16x3"):
+        with hipops.precision(mode):
+            params = [getattr(lstm, n).detach().to(DEV).requires_grad_(True) for n in LSTM_NAMES]
+            xg = x.to(DEV).requires_grad_(True)
+            y = Fh.blstm_layer(xg, lengths.to(torch.int32).to(DEV), params)
+            y.backward(dy.to(DEV))
+            torch.cuda.synchronize()
+        hipops.lstm_assert_no_timeouts()
+        e = {"out": rel_err(y.detach().cpu(), out.detach()), "dx": rel_err(xg.grad.cpu(), xr.grad)}
+        for n, p in zip(LSTM_NAMES, params):
+            e[n] = rel_err(p.grad.cpu(), getattr(l64, n).grad)
+        errs[mode] = e
+        for b, n in enumerate(lens):
+            assert torch.all(y[n:, b] == 0)
+    worst = {m: max(e.values()) for m, e in errs.items()}
+    print(f"[precision] T={T} B={B}: worst rel err vs fp64  f32 mode {worst['f32']:.2e} (out {errs['f32']['out']:.2e})   "
+          f"bf16x3 mode {worst['bf16x3']:.2e} (out {errs['bf16x3']['out']:.2e})")
+    assert worst["f32"] < 1e-5, errs["f32"]
+    assert worst["bf16x3"] < 1e-3 and errs["f32"]["out"] < errs["bf16x3"]["out"]
 
 
 def test_blstm_write_through_protocol_matches_default():

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from policy_gradient_asr_amd.train_step import (DataParallelStep, balance_by_frames, flatten_parameters,
+from policy_gradient_asr_amd.train_step import (FLAG_PAD, DataParallelStep, balance_by_frames, flatten_parameters,
                                                 shard_slice)
 
 
@@ -26,7 +26,17 @@ class ToyStepTwoBuckets(ToyStep):
     def backward(self, loss):
         loss.backward()
         self.reduce_upper(self.param_offset("2.weight"))
-        assert self._early is not None and self._early[0] == 6 * 5 + 5
+        assert self._early is not None and self._early[0] == FLAG_PAD + 6 * 5 + 5
+
+
+class ToyStepOneRankFails(ToyStepTwoBuckets):
+    """Rank 1 reports invalid gradients (a timed-out sweep) in its SECOND step only: the flag must reach every rank through
+    the gradient all-reduce, so that both replicas skip that update together."""
+    fail_rank, fail_call = 1, 1
+
+    def local_error_flag(self):
+        bad = dist.get_rank() == self.fail_rank and self.nstep == self.fail_call
+        return torch.tensor(1.0 if bad else 0.0)
 
 
 def make_model():
@@ -55,6 +65,43 @@ def _worker(rank, world, port, q, two_buckets):
         q.put((rank, st.flat.tolist(), st.gflat.tolist(), losses))   # by value: the worker exits right after
     finally:
         dist.destroy_process_group()
+
+
+def _worker_flag(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        st = ToyStepOneRankFails(make_model(), lr=1e-2, world_size=world)
+        x, y = make_data()
+        sl = shard_slice(8, rank, world)
+        snaps = []
+        for _ in range(3):
+            st.step(x[sl], y[sl])
+            snaps.append(st.flat.tolist())
+        q.put((rank, snaps, st.applied_steps(), st.nstep))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_error_flag_on_one_rank_skips_the_update_on_every_rank():
+    """the Adam guard must be global.  One rank flags its second step; both ranks must leave their
+    parameters untouched in that step, count two applied updates out of three calls, and stay bit-identical replicas."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_flag, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, snaps, applied, calls in res:
+        assert calls == 3 and applied == 2, (rank, calls, applied)
+        assert snaps[1] == snaps[0]              # the flagged step changed nothing, on the rank that did NOT fail too
+        assert snaps[2] != snaps[1]              # the next step is applied again
+    assert res[0][1] == res[1][1]                # replicas bit-identical after every step
 
 
 def _free_port():
@@ -93,6 +140,8 @@ def test_flatten_parameters_views():
     before = [p.detach().clone() for p in m.parameters()]
     flat, gflat = flatten_parameters(m)
     assert flat.numel() == sum(p.numel() for p in m.parameters())
+    flat_p, _ = flatten_parameters(make_model(), FLAG_PAD)
+    assert flat_p.numel() == flat.numel() + FLAG_PAD and float(flat_p[:FLAG_PAD].abs().sum()) == 0.0
     for p, b in zip(m.parameters(), before):
         assert torch.equal(p.detach(), b)
         assert p.data_ptr() >= flat.data_ptr() and p.grad.data_ptr() >= gflat.data_ptr()

@@ -100,6 +100,71 @@ def test_ctc_train_step_grads_vs_oracle_plumbing_config():
         assert rel_err(v.grad.cpu(), pr[rk].grad) < 1e-3, k
 
 
+def test_f32_mode_ctc_step_vs_fp64_oracle():
+    """precision="f32" (the reference's arithmetic: torch fp32 nn.Linear / nn.LSTM, model.py:38-44) on the plumbing config:
+    loss within 1e-6 and every parameter gradient within 1e-5 (Frobenius) / 5e-5 (max norm) of the torch-CPU model run in
+    FP64 on the same weights; the default bf16x3 mode is measured beside it."""
+    from policy_gradient_asr_amd import hipops
+    from policy_gradient_asr_amd.model import Seq2Seq
+    from policy_gradient_asr_amd.loss import pg_ctc_loss
+    B, F, T, V, L = 4, 80, 200, 29, 20
+    lens, tlens = [200, 170, 200, 120], [20, 15, 20, 9]
+    x, targets, fmask, tmask = _make(B, F, T, V, L, lens, tlens, 5)
+    p = model_ref.init_params(n_feats=F, vocab=V, seed=2)
+    pr = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    enc = model_ref.encoder_forward_torch(pr, x.double(), fmask)
+    lp = model_ref.head_forward_torch(pr, enc)
+    ref = torch.nn.functional.ctc_loss(lp, targets, torch.tensor(lens), torch.tensor(tlens), blank=0, reduction="mean")
+    ref.backward()
+    res = {}
+    for mode in ("f32", "bf16x3"):
+        m = Seq2Seq(V, n_feats=F)
+        m.load_state_dict({("encoder." + k if not k.startswith("head.") else k): v for k, v in p.items()}, strict=True)
+        m = m.to(DEV).eval()
+        with hipops.precision(mode):
+            logits, in_len = m.logits(x.to(DEV), fmask.to(DEV))
+            loss, nll, _, _ = pg_ctc_loss(logits, in_len, targets.to(torch.int32).to(DEV),
+                                          torch.tensor(tlens, dtype=torch.int32, device=DEV), lam=0.0)
+            loss.backward()
+            torch.cuda.synchronize()
+        fro, mx = 0.0, 0.0
+        for k, v in m.named_parameters():
+            rk = k[len("encoder."):] if k.startswith("encoder.") else k
+            a, r = v.grad.cpu().double(), pr[rk].grad
+            fro = max(fro, float((a - r).norm() / r.norm())); mx = max(mx, rel_err(a, r))
+        res[mode] = (abs(float(loss) - float(ref)) / abs(float(ref)), fro, mx)
+        print(f"[precision] {mode}: loss rel err {res[mode][0]:.2e}, worst gradient Frobenius {fro:.2e}, max norm {mx:.2e}")
+    assert res["f32"][0] < 1e-6 and res["f32"][1] < 1e-5 and res["f32"][2] < 5e-5, res
+    assert res["bf16x3"][0] < 1e-3 and res["bf16x3"][2] < 1e-3, res
+
+
+def test_trainer_precision_modes_and_limits():
+    """PolicyGradientTrainer(precision=...) runs its steps in that mode and leaves the process-wide mode alone; the
+    compiled-in limits are reported as ValueErrors with the reason, not as a status from deep inside the step."""
+    from policy_gradient_asr_amd import hipops
+    from policy_gradient_asr_amd.model import Seq2Seq, weights
+    from policy_gradient_asr_amd.train_step import PolicyGradientTrainer
+    B, F, T, V, L = 4, 80, 64, 29, 6
+    x, targets, fmask, tmask = _make(B, F, T, V, L, [64, 50, 64, 33], [6, 5, 6, 3], 2)
+    losses = {}
+    for mode in ("bf16x3", "f32"):
+        torch.manual_seed(0)
+        m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(DEV).eval()
+        tr = PolicyGradientTrainer(m, lr=1e-3, lam=0.0, seed=1, precision=mode)
+        losses[mode] = [float(tr.step(x.to(DEV), targets.to(DEV), fmask.to(DEV), tmask.to(DEV))) for _ in range(3)]
+        assert hipops.get_precision() == "bf16x3"
+        assert tr.applied_steps() == 3
+    assert losses["f32"][0] == pytest.approx(losses["bf16x3"][0], rel=1e-4) and losses["f32"] != losses["bf16x3"]
+    with pytest.raises(ValueError):
+        PolicyGradientTrainer(m, precision="fp8")
+    big = torch.zeros(129, F, 8, device=DEV)
+    with pytest.raises(ValueError, match="local batch"):
+        tr.step(big, torch.ones(129, 2, dtype=torch.int64, device=DEV), torch.ones(129, 8, device=DEV), torch.ones(129, 2, dtype=torch.int64, device=DEV))
+    m65 = Seq2Seq(65, n_feats=F).to(DEV)
+    with pytest.raises(ValueError, match="alphabet"):
+        PolicyGradientTrainer(m65).step(x.to(DEV), targets.to(DEV), fmask.to(DEV), tmask.to(DEV))
+
+
 def test_pg_train_step_grads_vs_oracle_with_shared_paths():
     """lam=1: the discrete choices (sampled + greedy paths) must agree with the oracle's on the
     oracle's own logits; gradients then agree to 1e-3."""
@@ -149,16 +214,19 @@ def test_custom_nll_loss_dropin_vs_reference_golden(golden_dir):
         assert out.requires_grad and float(out) == pytest.approx(row["loss_ignore_none"], rel=1e-6)
 
 
-def _pg_step_vs_oracle(B, F, T, V, L, lens, tlens, seed, beam=0, threads=None, share_choices=False):
+def _pg_step_vs_oracle(B, F, T, V, L, lens, tlens, seed, beam=0, threads=None, share_choices=False, beam_spot_checks=2):
     """One lambda = 1 step of the whole model against the CPU path.  The device makes its discrete choices (sampled
     path, baseline hypothesis) on ITS logits, the oracle on the ORACLE's logits.
       share_choices = False (small shapes): they must agree outright -- rewards exact.
-      share_choices = True (32 x 1000 frames): two logit tensors that differ by 1e-5 cannot give bit-identical samples
-        and arg-maxima in every one of 32000 frames (a draw within 1e-5 of a CDF step, a 1e-5 tie between two symbols),
-        so the oracle takes the device's frame labels -- after checking that they agree with its own in all but a
-        handful of frames -- and everything downstream of the labels is recomputed independently: collapse, edit
-        distance and rewards (exact), d(logits), and the backward pass of the torch-CPU model (1e-3)."""
-    from policy_gradient_asr_amd import hipops
+      share_choices = True (32 x 1000 frames): two fp32 evaluations that differ by 1e-5 cannot make bit-identical discrete
+        choices in every one of 32000 frames / 16 M activations (a draw within 1e-5 of a CDF step, a 1e-5 tie between two
+        symbols, a pre-activation of the input layer that is zero to rounding and lands on the other side of leaky_relu).
+        So the oracle takes the device's choices -- frame labels, beam hypothesis, leaky_relu sides -- AFTER checking that
+        they agree with its own in all but a handful of places (counts asserted and printed), and everything downstream
+        of the choices is recomputed independently: collapse, edit distance and rewards (exact), d(logits), and the
+        backward pass of the torch-CPU model.  Every parameter gradient is then held to 1e-3 entrywise (max norm), the
+        input layer's included."""
+    from policy_gradient_asr_amd import hipops, functional as Fh
     from policy_gradient_asr_amd.model import Seq2Seq
     from policy_gradient_asr_amd.loss import pg_ctc_loss
     if threads:
@@ -166,11 +234,23 @@ def _pg_step_vs_oracle(B, F, T, V, L, lens, tlens, seed, beam=0, threads=None, s
     x, targets, fmask, tmask = _make(B, F, T, V, L, lens, tlens, seed)
     p = model_ref.init_params(n_feats=F, vocab=V, seed=seed + 1)
     pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
-    enc = model_ref.encoder_forward_torch(pr, x, fmask, packed=any(n != T for n in lens))
-    logits_ref = model_ref.head_logits_torch(pr, enc)
     m = Seq2Seq(V, n_feats=F)
     m.load_state_dict({("encoder." + k if not k.startswith("head.") else k): v for k, v in p.items()}, strict=True)
     m = m.to(DEV).eval()
+    packed = any(n != T for n in lens)
+    side = None
+    if share_choices:
+        # the device's leaky_relu sides (model.py:50): sign of the affine's output, the same launch the model makes
+        with torch.no_grad():
+            y_dev = Fh.InstNormAffineFn.apply(x.to(DEV), m.encoder.input_layer.weight, m.encoder.input_layer.bias)
+            side = (y_dev > 0).permute(1, 0, 2).cpu()          # (B,T,512)
+            own = torch.nn.functional.linear(model_ref.instance_norm(x).transpose(1, 2), p["input_layer.weight"], p["input_layer.bias"]) > 0
+            valid = fmask.bool()[:, :, None]
+            n_flip = int(((side != own) & valid).sum())
+        print(f"[parity] leaky_relu sides that differ between device and torch-CPU fp32: {n_flip} of {int(valid.sum()) * 512}")
+        assert n_flip <= 32, n_flip          # ~1e-7 relative on 16 M pre-activations: a handful
+    enc = model_ref.encoder_forward_torch(pr, x, fmask, packed=packed, leaky_side=side)
+    logits_ref = model_ref.head_logits_torch(pr, enc)
     logits, in_len = m.logits(x.to(DEV), fmask.to(DEV))
     loss, nll, R_s, R_b = pg_ctc_loss(logits, in_len, targets.to(torch.int32).to(DEV),
                                       torch.tensor(tlens, dtype=torch.int32, device=DEV), lam=1.0, seed=3, offset=1, beam=beam)
@@ -181,18 +261,35 @@ def _pg_step_vs_oracle(B, F, T, V, L, lens, tlens, seed, beam=0, threads=None, s
     tg = targets.numpy()
     paths, _, _ = decode_ref.sample_paths(lg, seed=3, offset=1)
     greedy_frames = np.argmax(lg, axis=2)
+    dev_hyp = None
     if share_choices:
-        d_greedy, d_sample = hipops.frame_argmax_sample(hipops.log_softmax_rows(logits.detach().contiguous()), seed=3, offset=1)
+        lp_dev = hipops.log_softmax_rows(logits.detach().contiguous())
+        d_greedy, d_sample = hipops.frame_argmax_sample(lp_dev, seed=3, offset=1)
         d_greedy, d_sample = d_greedy.cpu().numpy().astype(np.int64), d_sample.cpu().numpy().astype(np.int64)
-        assert (d_sample != paths).sum() <= 1e-3 * T * B and (d_greedy != greedy_frames).sum() <= 1e-3 * T * B
-        paths, greedy_frames = d_sample, d_greedy
+        fm = (np.arange(T)[:, None] < il[None, :])
+        n_s, n_g = int(((d_sample != paths) & fm).sum()), int(((d_greedy != greedy_frames) & fm).sum())
+        print(f"[parity] frame labels that differ: sampled {n_s}, arg-max {n_g} of {int(fm.sum())}")
+        assert n_s <= 1e-3 * fm.sum() and n_g <= 1e-3 * fm.sum()
+        paths, greedy_frames = np.where(fm, d_sample, paths), np.where(fm, d_greedy, greedy_frames)
+        if beam:
+            # the device's beam hypotheses (after collapse_fn) are shared too; `beam_spot_checks` of them are checked against
+            # the pure-Python prefix search on the DEVICE's log-probs (test_beam_headline_size_properties covers all 32)
+            tok, tok_len, _ = hipops.ctc_beam_search(lp_dev, in_len, beam=beam, collapse=True)
+            tok, tok_len = tok.cpu().numpy(), tok_len.cpu().numpy()
+            dev_hyp = [list(tok[b, :tok_len[b]]) for b in range(B)]
+            lp_np = lp_dev.double().cpu().numpy()
+            for b in sorted(range(B), key=lambda i: lens[i])[:beam_spot_checks]:
+                hyp, _ = decode_ref.prefix_beam_search(np.exp(lp_np[:lens[b], b]), beam_size=beam)
+                assert [h for i, h in enumerate(hyp) if i == 0 or h != hyp[i - 1]] == dev_hyp[b], b
     Lf = np.maximum(tl_, 1).astype(np.float64)
     wRs, wRb = np.zeros(B), np.zeros(B)
     lp64 = ctc_ref.log_softmax(lg, axis=2)
     for b in range(B):
         y = list(tg[b][:tlens[b]])
         wRs[b] = -decode_ref.edit_dist(y, decode_ref.collapse_path(paths[:lens[b], b]))[0] / Lf[b]
-        if beam:      # the reference's reward hypothesis (policy_grad.py:6-8): prefix beam search -> collapse_fn -> edit distance
+        if beam and dev_hyp is not None:
+            hyp = dev_hyp[b]
+        elif beam:      # the reference's reward hypothesis (policy_grad.py:6-8): prefix beam search -> collapse_fn -> edit distance
             hyp, _ = decode_ref.prefix_beam_search(np.exp(lp64[:lens[b], b]), beam_size=beam)
             hyp = [h for i, h in enumerate(hyp) if i == 0 or h != hyp[i - 1]]
         else:
@@ -209,22 +306,15 @@ def _pg_step_vs_oracle(B, F, T, V, L, lens, tlens, seed, beam=0, threads=None, s
     np.testing.assert_allclose(R_s.cpu().numpy(), wRs, rtol=1e-6)
     assert abs(float(loss) - w_loss) / abs(w_loss) < 1e-3
     logits_ref.backward(torch.from_numpy(w_grad).float())
-    worst = 0.0
+    errs = {}
     for k, v in m.named_parameters():
         rk = k[len("encoder."):] if k.startswith("encoder.") else k
-        if rk.startswith("input_layer.") and share_choices:
-            # The input layer sits behind leaky_relu, whose derivative is a step function of the pre-activation's sign.
-            # Two fp32 evaluations of 16 M pre-activations disagree on the sign of the few that are zero to rounding
-            # (expected ~2-3 at 1e-7 relative), and each disagreement scales ONE of the 32000 random-signed summands
-            # of a bias-gradient entry by 100: ~5e-3 of that entry under a REINFORCE gradient (torch-CPU fp32 against
-            # torch-CPU fp64 shows the same).  Those two tensors are therefore held to 1e-3 in the Frobenius norm and
-            # to 1e-2 entrywise; every other tensor to 1e-3 entrywise (max norm).
-            a, r = v.grad.cpu().double(), pr[rk].grad.double()
-            assert float((a - r).norm() / r.norm()) < 1e-3, rk
-            assert rel_err(a, r) < 1e-2, rk
-            continue
-        worst = max(worst, rel_err(v.grad.cpu(), pr[rk].grad))
-    assert worst < 1e-3, worst
+        errs[rk] = rel_err(v.grad.cpu(), pr[rk].grad)
+    worst = max(errs, key=errs.get)
+    print(f"[parity] loss rel err {abs(float(loss) - w_loss) / abs(w_loss):.2e}; worst parameter gradient {worst} {errs[worst]:.2e}; "
+          f"input_layer.weight {errs['input_layer.weight']:.2e}, input_layer.bias {errs['input_layer.bias']:.2e}")
+    assert errs[worst] < 1e-3, (worst, errs[worst])
+    return errs
 
 
 def test_pg_step_with_beam_reward_vs_oracle():
@@ -238,6 +328,18 @@ def test_pg_step_full_size_lambda1_vs_oracle():
     loss and every parameter gradient within 1e-3 of the CPU path."""
     _pg_step_vs_oracle(32, 80, 1000, 29, 100, [1000] * 32, [100] * 32, seed=31, threads=min(16, os.cpu_count() or 1),
                        share_choices=True)
+
+
+def test_bucketed_full_size_step():
+    """configs[4] as a whole step at full size: B = 32, lengths U[500,1000] (L = T/10), the reference's reward hypothesis
+    (prefix beam search, beam 16 -> collapse_fn -> edit distance, policy_grad.py:6-8), eval mode; loss and every parameter
+    gradient within 1e-3 of the torch-CPU model with the PACKED LSTM exactly as model.py:52-55 calls it, discrete choices
+    shared (see _pg_step_vs_oracle)."""
+    g = torch.Generator().manual_seed(77)
+    lens = torch.randint(500, 1001, (32,), generator=g).tolist()
+    lens[5] = 1000                                       # Tmax is reached
+    _pg_step_vs_oracle(32, 80, 1000, 29, 100, lens, [n // 10 for n in lens], seed=41, beam=16,
+                       threads=min(16, os.cpu_count() or 1), share_choices=True)
 
 
 def test_trainer_with_beam_reward_runs_and_matches_loss_fn():
@@ -353,7 +455,8 @@ def test_upper_bucket_is_complete_where_its_allreduce_is_issued():
         torch.cuda.synchronize()
         split, snap = snaps.pop()
         assert not snaps
-        assert split == tr.param_offset("encoder.blstm.weight_ih_l1") == 512 * 80 + 512 + 2 * (1024 * (512 + 256) + 2048)
+        from policy_gradient_asr_amd.train_step import FLAG_PAD
+        assert split == tr.param_offset("encoder.blstm.weight_ih_l1") == FLAG_PAD + 512 * 80 + 512 + 2 * (1024 * (512 + 256) + 2048)
         assert torch.equal(snap, tr.gflat[split:])
         assert float(snap.abs().sum()) > 0 and float(tr.gflat[:split].abs().sum()) > 0
 
