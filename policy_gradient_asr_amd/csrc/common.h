@@ -60,3 +60,32 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+
+// ---- internal (not part of the C ABI): the 256 x 256-tile TN product of gemm_dma.hip, reached through pgasr_gemm_f32 ----
+// partial[z][M][N] = alpha * sum_{k in slab(z)} A_b[k][m] * B_b[k][n],  z = b * splitk + s, slab(z) = [s*kper, min(K, (s+1)*kper))
+// bf16x3 arithmetic.  Requirements (checked by pgasr_internal_tn256_ok): M % 256 == 0, N % 256 == 0, K % 32 == 0,
+// kper % 32 == 0, lda % 4 == 0, ldb % 4 == 0, batch strides % 4 == 0, 16-byte aligned A / B.
+struct PgasrTn256Args {
+    const float* A; const float* B; float* partial;
+    int M, N, K, lda, ldb;
+    long long sA, sB;
+    int batch, splitk, kper;
+    float alpha;
+    unsigned* queue;            // zeroed word: work items are drawn from it (queue mode), or nullptr (item = blockIdx.x)
+    const unsigned* xcc_busy;   // queue mode: workgroups on an XCD whose word is non-zero take no item
+};
+bool pgasr_internal_tn256_ok(const PgasrTn256Args& a);
+int pgasr_internal_tn256_launch(PgasrTn256Args a, int masked_then_unmasked, hipStream_t st);
+
+// ---- internal: the 8-wave 256 x 256 x3w kernel of gemm_c256.hip (cooperative A split), reached through pgasr_gemm_x3w_f32 / _feed_f32 ----
+struct PgasrX3cArgs {
+    const float* A; const unsigned short* Whi; const unsigned short* Wlo; float* C;
+    int M, N, K, lda, ldc;
+    const float* bias; const float* dact_y; float slope;
+    int feed;                   // 0: plain launch (one workgroup per tile); 1: persistent feed-ahead launch (two passes)
+    unsigned* queue; const unsigned* xcc_busy; unsigned* tiles_done;
+    int mt_count, nt_count, order, quarters, split_tiles;
+    float* slabs; unsigned* arrive;
+};
+size_t pgasr_internal_x3c_slab_bytes();
+int pgasr_internal_x3c_launch(const PgasrX3cArgs& a, hipStream_t st);

@@ -615,7 +615,21 @@ static int gemm_launch(GemmArgs& g, int transA, int transB, int sum_batches, int
     }
     const unsigned ntiles_q = grid.x * grid.y * grid.z;
 
-    if (precision == 1) {
+    // weight-gradient shaped TN products (both operands k-major fp32, K long, split over K): the 256 x 256 LDS-DMA tile
+    // of gemm_dma.hip writes the same raw partial slabs; the reduce below is shared
+    bool done_tn256 = false;
+    if (precision == 1 && transA && !transB && use_partial && g.norm_operand == 0) {
+        PgasrTn256Args t{g.A, g.B, g.partial, g.M, g.N, g.K, g.lda, g.ldb, g.sA, g.sB, g.batch, g.splitk, g.kper, g.alpha,
+                         queue_mode ? g.queue : nullptr, queue_mode ? g.xcc_busy : nullptr};
+        if (pgasr_internal_tn256_ok(t)) {
+            const int st_ = pgasr_internal_tn256_launch(t, queue_mode ? 1 : 0, st);
+            if (st_ != PGASR_OK) return st_;
+            done_tn256 = true;
+        }
+    }
+    if (done_tn256) {
+    }
+    else if (precision == 1) {
         if (queue_mode) {
             // pass 0: masked, enough workgroups that the allowed XCDs alone can cover every tile under
             // round-robin dealing; pass 1: unmasked sweeper for any tiles left over (normally all exit at once)

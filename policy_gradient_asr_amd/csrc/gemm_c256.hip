@@ -1,0 +1,347 @@
+// C[M,N] = A[M,K] * W[N,K]^T (+ bias[n]) (* leaky'(dact_y[m,n])) -- the LSTM input projections X W_ih^T and their
+// input gradients dG W_ih (model.py:39-44) -- third structure (round 3), built from what the first two measured:
+//
+//   * gemm_dma.hip's 256 x 128 kernel (8 waves x 64 x 64): every wave re-splits the fp32 A fragments it shares with the
+//     other column wave (VALU ~28 % busy), MFMA pipe 35 %;
+//   * its 256 x 256 / 4-wave variant (128 x 128 per wave, one wave per SIMD): half the split work per MFMA, but ONE wave
+//     per SIMD issues everything in order -- LDS-DMA (~60 cycles each), splits, fragment reads and MFMAs add instead of
+//     overlapping: 1.6-1.9 us per 16-deep k-step against 0.65 us of MFMA time (PMC: 4.4 VALU instructions per MFMA,
+//     35 % of wave cycles in issue stalls).  With DMA and MFMA switched off in turn: DMA path alone 0.9 us per step,
+//     MFMA + VALU alone 1.3 us.
+//
+// Here: 256 x 256 tile, EIGHT waves (two per SIMD, 128 x 64 each, 128 accumulator registers), 32-deep steps.
+//   * fp32 A is split into bf16 hi / lo ONCE per workgroup: every thread loads 4 x 16 B of the NEXT step's A rows into
+//     registers (fully coalesced: 8 lanes per 128-byte row segment), converts them and writes the two planes into an LDS
+//     buffer ([row][32 k] bf16, 64-byte rows, chunk ^= (row >> 2) & 3) -- 48 VALU instructions per thread and step instead
+//     of 112 per wave and 16-deep step; A fragments are then plain ds_read_b128 like the W fragments;
+//   * W planes (pre-split, L2-resident) come by LDS-DMA, one 32-deep stage ahead (2 stages);
+//   * ONE raw s_barrier per 32-deep step (48 MFMAs per wave between barriers); LDS: 2 x 32 KB A planes + 2 x 32 KB W = 128 KB;
+//   * the two waves of a SIMD run the step's two halves in OPPOSITE order (waves 0-3: convert, then multiply; waves 4-7:
+//     multiply, then convert), so that one wave's VALU / LDS-write phase sits beside its partner's MFMA phase;
+//   * branch-free epilogue (buffer stores, rows past M dropped by the resource's range check).
+// One accumulation chain over K per tile; only the feed's first tiles are fixed-order sums of four K-quarters (slabs), and
+// the sequential order of the same product runs the same kernel (functional.py), so both orders give the same bits.
+// Preconditions: K % 32 == 0 (quarters: K % 128 == 0), N % 256 == 0, lda % 4 == 0, 16-byte aligned A / planes,
+// M * ldc * 4 < 2^32 and M * lda * 4 < 2^32.
+#include "common.h"
+#include "x3w_common.h"
+
+namespace {
+namespace c256 {
+constexpr int TM = 256, TN = 256, TK = 32, THREADS = 512;
+constexpr int AP_BYTES = TM * TK * 2;            // one A plane of one buffer: 16 KB
+constexpr int ABUF_BYTES = 2 * AP_BYTES;         // hi | lo
+constexpr int WP_BYTES = TN * TK * 2;            // one W plane of one stage: 16 KB
+constexpr int WSTAGE_BYTES = 2 * WP_BYTES;       // hi | lo
+constexpr int LDS_W = 2 * ABUF_BYTES;            // [A buffer 0][A buffer 1][W stage 0][W stage 1][mailbox]
+constexpr int LDS_BYTES = LDS_W + 2 * WSTAGE_BYTES;      // 128 KB
+constexpr int SLAB_FLOATS = 128 * THREADS;       // one parked accumulator set: 256 KB
+
+struct Frag { u32x4_t ah[4], al[4], bh[2], bl[2]; };
+
+__device__ __forceinline__ void read_frags(Frag& f, unsigned a0, unsigned a1, unsigned a2, unsigned a3, unsigned b0, unsigned b1) {
+    static_assert(AP_BYTES == 16384 && WP_BYTES == 16384, "plane offsets are spelled in the asm below");
+    asm volatile("ds_read_b128 %0, %12\n\t"
+                 "ds_read_b128 %1, %12 offset:16384\n\t"
+                 "ds_read_b128 %8, %16\n\t"
+                 "ds_read_b128 %9, %16 offset:16384\n\t"
+                 "ds_read_b128 %10, %17\n\t"
+                 "ds_read_b128 %11, %17 offset:16384\n\t"
+                 "ds_read_b128 %2, %13\n\t"
+                 "ds_read_b128 %3, %13 offset:16384\n\t"
+                 "ds_read_b128 %4, %14\n\t"
+                 "ds_read_b128 %5, %14 offset:16384\n\t"
+                 "ds_read_b128 %6, %15\n\t"
+                 "ds_read_b128 %7, %15 offset:16384"
+                 : "=&v"(f.ah[0]), "=&v"(f.al[0]), "=&v"(f.ah[1]), "=&v"(f.al[1]), "=&v"(f.ah[2]), "=&v"(f.al[2]),
+                   "=&v"(f.ah[3]), "=&v"(f.al[3]), "=&v"(f.bh[0]), "=&v"(f.bl[0]), "=&v"(f.bh[1]), "=&v"(f.bl[1])
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1)
+                 : "memory");
+}
+__device__ __forceinline__ void wait_frags(Frag& f) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f.ah[0]), "+v"(f.al[0]), "+v"(f.ah[1]), "+v"(f.al[1]), "+v"(f.ah[2]), "+v"(f.al[2]),
+                   "+v"(f.ah[3]), "+v"(f.al[3]), "+v"(f.bh[0]), "+v"(f.bl[0]), "+v"(f.bh[1]), "+v"(f.bl[1])
+                 :: "memory");
+}
+// two 8-byte LDS stores (hi plane, lo plane = + 16 KB) hidden from hipcc, which would drain the LDS-DMA in flight
+// (s_waitcnt vmcnt(0)) in front of any LDS access it can see
+__device__ __forceinline__ void write_planes(unsigned addr, unsigned h0, unsigned h1, unsigned l0, unsigned l1) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u2;
+    const u2 h = {h0, h1}, l = {l0, l1};
+    asm volatile("ds_write_b64 %0, %1\n\t"
+                 "ds_write_b64 %0, %2 offset:16384" :: "v"(addr), "v"(h), "v"(l) : "memory");
+}
+
+template <bool FEED>
+__global__ __launch_bounds__(THREADS) void gemm_x3c_kernel(DmaGemmArgs g) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];   // the ONLY LDS object
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 2, wn = w & 3;
+    const int nk = g.K / TK;
+    if (FEED && g.xcc_busy) {       // a workgroup on one of the sweep's XCDs leaves at once (placement is read, not assumed)
+        const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;
+        if (__hip_atomic_load(g.xcc_busy + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int diag = FEED ? 0 : g.quarters;      // plain launches carry a diagnostic code there (PGASR_X3W_DIAG; results invalid)
+  for (;;) {
+    int tbx, tby;
+    int kt0 = 0, kt1 = nk, qpart = -1;      // step range of this work item; qpart >= 0: one quarter of a split tile
+    unsigned tile = 0;
+    if (FEED) {
+        unsigned* mailbox = reinterpret_cast<unsigned*>(smem + LDS_BYTES);
+        if (tid == 0) *mailbox = __hip_atomic_fetch_add(g.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned t = *mailbox;
+        __syncthreads();
+        const unsigned S = (unsigned)g.split_tiles, ntot = (unsigned)g.mt_count * (unsigned)g.nt_count;
+        if (t >= ntot + 3u * S) return;             // 4 S quarter items, then the remaining ntot - S whole tiles
+        if (t < 4u * S) { tile = t >> 2; qpart = (int)(t & 3u); kt0 = qpart * (nk >> 2); kt1 = kt0 + (nk >> 2); }
+        else tile = t - 3u * S;
+        const int half = g.nt_count >> 1, grp = (int)(tile / (unsigned)g.nt_count), j = (int)(tile % (unsigned)g.nt_count);
+        tbx = j;
+        tby = ((j < half) != (g.order != 0)) ? grp : g.mt_count - 1 - grp;
+    } else {
+        swizzled_tile(tbx, tby);
+    }
+    const int m0 = tby * TM, n0 = tbx * TN;
+
+    // ---- A: lane -> (row within an 8-row group, 16-byte chunk of the step's 128-byte row segment); wave w owns rows 32 w .. 32 w + 31
+    const int rsub = lane >> 3, ac = lane & 7;
+    unsigned aoff[4];           // byte offsets into A of (row, chunk) at k = 0 (rows past M clamped: their products are never stored)
+    unsigned apw[4];            // byte offsets into an A-plane buffer (hi plane) of the 8 bytes this lane writes per row
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = w * 32 + j * 8 + rsub;
+        int gm = m0 + r; gm = gm < g.M ? gm : g.M - 1;
+        aoff[j] = (unsigned)(((size_t)gm * g.lda + ac * 4) * 4);
+        apw[j] = (unsigned)(r * 64 + (((ac >> 1) ^ ((r >> 2) & 3)) * 16) + (ac & 1) * 8);
+    }
+    // ---- W planes by LDS-DMA: piece p = 16 rows x 64 B; wave w moves pieces w and w + 8 of either plane
+    const unsigned short *ph[2], *pl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 16 * (w + 8 * j) + (lane >> 2), cp = lane & 3, c = cp ^ ((row >> 2) & 3);
+        const size_t o = (size_t)(n0 + row) * g.K + c * 8;
+        ph[j] = g.Whi + o; pl[j] = g.Wlo + o;
+    }
+    auto issue_w = [&](int kt, int stage) {      // ALWAYS 4 wave-instructions (k clamped), so the counted waits are exact
+        const int k0 = (kt < nk ? kt : nk - 1) * TK;
+        unsigned char* ws = smem + LDS_W + stage * WSTAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma16(ph[j] + k0, ws + (w + 8 * j) * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma16(pl[j] + k0, ws + WP_BYTES + (w + 8 * j) * 1024);
+    };
+    u32x4_t araw[4];
+    // ALWAYS 4 loads, in inline asm: a load hipcc can see is waited for with s_waitcnt vmcnt(0) where its registers are
+    // handed to the asm wait below -- which would also drain the W pieces issued just before (seen in the .s)
+    auto load_a = [&](int kt) {
+        const unsigned kb = (unsigned)((kt < nk ? kt : nk - 1) * TK * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(araw[j]) : "v"(aoff[j] + kb), "s"(g.A) : "memory");
+    };
+    auto convert_a = [&](int buf) {               // araw -> hi / lo planes of buffer `buf`
+        const unsigned base = lds0 + (unsigned)buf * ABUF_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned h0, l0, h1, l1;
+            split2(__uint_as_float(araw[j].x), __uint_as_float(araw[j].y), h0, l0);
+            split2(__uint_as_float(araw[j].z), __uint_as_float(araw[j].w), h1, l1);
+            write_planes(base + apw[j], h0, h1, l0, l1);
+        }
+    };
+
+    // ---- fragment read offsets (k-step 0 of a stage; k-step 1 = ^ 32) ----
+    const int fr = lane & 31, fh = lane >> 5;
+    unsigned offA[4], offB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wm * 128 + i * 32 + fr;
+        offA[i] = (unsigned)(row * 64 + ((fh ^ ((row >> 2) & 3)) * 16));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = wn * 64 + j * 32 + fr;
+        offB[j] = (unsigned)(LDS_W + n * 64 + ((fh ^ ((n >> 2) & 3)) * 16));
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto multiply = [&](int cur) {                // the step's 48 MFMAs on A buffer `cur`, W stage `cur`
+        const unsigned ab = lds0 + (unsigned)cur * ABUF_BYTES, wb = lds0 + (unsigned)cur * WSTAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag f;
+            const unsigned x = ks ? 32u : 0u;
+            read_frags(f, (ab + offA[0]) ^ x, (ab + offA[1]) ^ x, (ab + offA[2]) ^ x, (ab + offA[3]) ^ x, (wb + offB[0]) ^ x, (wb + offB[1]) ^ x);
+            wait_frags(f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, f.ah[i]), al = __builtin_bit_cast(bf16x8_t, f.al[i]);
+                    const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, f.bh[j]), bl = __builtin_bit_cast(bf16x8_t, f.bl[j]);
+                    if (!FEED && (diag & 2)) { asm volatile("" :: "v"(ah), "v"(al), "v"(bh), "v"(bl)); continue; }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    // ---- prologue: A planes of the first step, W stage of the first step, A registers of the second ----
+    load_a(kt0);
+    issue_w(kt0, 0);
+    asm volatile("s_waitcnt vmcnt(4)" : "+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[3]) :: "memory");   // the A loads (older) are in
+    convert_a(0);
+    load_a(kt0 + 1);
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");        // W stage 0 landed (my pieces), my plane stores done
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        issue_w(kt + 1, cur ^ 1);                 // the stage everybody finished reading before the barrier just passed
+        __builtin_amdgcn_sched_barrier(0);
+        if (w < 4) {
+            // outstanding, oldest first: A loads of step kt + 1 (4), the W pieces just issued (4)
+            if (FEED || !(diag & 1))
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[3]) :: "memory");
+            convert_a(cur ^ 1);
+            load_a(kt + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(cur);
+        } else {
+            multiply(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            if (FEED || !(diag & 1))
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[3]) :: "memory");
+            convert_a(cur ^ 1);
+            load_a(kt + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // my W pieces of step kt + 1 have landed (the 4 A loads behind them may still fly), my plane stores are done
+        if (FEED || !(diag & 1)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[3]) :: "memory");   // the loads of the step behind the last one (discarded)
+
+    if (FEED && qpart >= 0) {
+        // one quarter of a split tile: park the accumulators (thread-major: a wave instruction stores 256 contiguous
+        // bytes) write-through, count the arrival; the LAST of the four sums the quarters in index order and goes on to
+        // the epilogue, the others take their next work item
+        __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(g.slabs, 0, (int)(unsigned)((size_t)g.split_tiles * 4 * SLAB_FLOATS * 4), 0x00020000);
+        const unsigned sbq = (tile * 4u + (unsigned)qpart) * 128u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), srs, ((sbq + (unsigned)((i * 2 + j) * 16 + r)) * 512u + (unsigned)tid) * 4u, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* mailbox = reinterpret_cast<unsigned*>(smem + LDS_BYTES);
+        if (tid == 0) *mailbox = __hip_atomic_fetch_add(g.arrive + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned before = *mailbox;
+        __syncthreads();
+        if (before != 3u) continue;
+        // total = ((q0 + q1) + q2) + q3, whoever arrives last
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                            srs, (((tile * 4u + (unsigned)qq) * 128u + (unsigned)((i * 2 + j) * 16 + r)) * 512u + (unsigned)tid) * 4u, 0, 16));
+                        t = qq == 0 ? v : t + v;
+                    }
+                    acc[i][j][r] = t;
+                }
+    }
+
+    // epilogue (branch-free): 32x32 accumulator layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int cl = lane & 31, rq = lane >> 5;
+    __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(unsigned)((size_t)g.M * g.ldc * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dact_y ? g.dact_y : g.C), 0, (int)(unsigned)((size_t)g.M * g.ldc * 4), 0x00020000);
+    float bsum[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bsum[j] = g.bias ? g.bias[n0 + wn * 64 + j * 32 + cl] : 0.f;
+    if (g.dact_y) {            // two straight-line loops: a merge point inside one brings a per-tile s_waitcnt vmcnt(0) back
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned o0 = (unsigned)(((size_t)(m0 + wm * 128 + i * 32 + 4 * rq) * g.ldc + n0 + wn * 64 + j * 32 + cl) * 4);
+                float f[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    f[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4), 0, 0)) > 0.f ? 1.f : g.slope;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[i][j][r] + bsum[j]) * f[r]), crs, o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4), 0, FEED ? 16 : 0);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned o0 = (unsigned)(((size_t)(m0 + wm * 128 + i * 32 + 4 * rq) * g.ldc + n0 + wn * 64 + j * 32 + cl) * 4);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r] + bsum[j]), crs, o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4), 0, FEED ? 16 : 0);
+            }
+    }
+    if (!FEED) return;
+    // the tile's stores have reached memory (vmcnt(0) in every wave, then the barrier) before it is counted; the
+    // barrier also retires every DMA of this tile before the next one reuses the stages
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        __hip_atomic_fetch_add(g.tiles_done + (tbx < (g.nt_count >> 1) ? 0 : g.mt_count) + tby, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+}  // namespace c256
+}  // namespace
+
+// ---- internal entry points used by gemm_dma.hip's C ABI functions ----
+size_t pgasr_internal_x3c_slab_bytes() { return (size_t)c256::SLAB_FLOATS * 4; }
+
+int pgasr_internal_x3c_launch(const PgasrX3cArgs& a, hipStream_t st) {
+    DmaGemmArgs g{a.A, a.Whi, a.Wlo, a.C, a.M, a.N, a.K, a.lda, a.ldc, a.bias, a.dact_y, a.slope,
+                  a.queue, a.xcc_busy, a.tiles_done, a.mt_count, a.nt_count, a.order, a.quarters, a.split_tiles, a.slabs, a.arrive};
+    if (!a.feed) {
+        const size_t lds = (size_t)c256::LDS_BYTES;
+        if (hipFuncSetAttribute((const void*)c256::gemm_x3c_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PGASR_ERR_LAUNCH;
+        PGASR_LAUNCH_KERNEL(c256::gemm_x3c_kernel<false>, dim3((unsigned)(a.N / c256::TN), (unsigned)((a.M + c256::TM - 1) / c256::TM)), dim3(c256::THREADS), lds, st, g);
+        PGASR_CHECK_LAUNCH();
+        return PGASR_OK;
+    }
+    const size_t lds = (size_t)c256::LDS_BYTES + 16;
+    if (hipFuncSetAttribute((const void*)c256::gemm_x3c_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PGASR_ERR_LAUNCH;
+    for (int pass = 0; pass < 2; ++pass) {     // one persistent workgroup per CU; pass 1 ignores the busy counters
+        if (pass == 1) g.xcc_busy = nullptr;
+        PGASR_LAUNCH_KERNEL(c256::gemm_x3c_kernel<true>, dim3(256), dim3(c256::THREADS), lds, st, g);
+        PGASR_CHECK_LAUNCH();
+    }
+    return PGASR_OK;
+}

@@ -26,6 +26,7 @@
 // K % 32 == 0, N % 128 == 0, lda % 4 == 0, 16-byte aligned A / planes.  M is arbitrary (rows are
 // clamped on load and masked on store).
 #include "common.h"
+#include "x3w_common.h"
 #include <type_traits>
 
 namespace {
@@ -34,56 +35,6 @@ constexpr int TM = 256, TN = 128, TK = 32, NST = 3, DMA_THREADS = 512;
 constexpr int A_BYTES = TM * TK * 4;                 // 32 KB raw fp32
 constexpr int P_BYTES = TN * TK * 2;                 // 8 KB per bf16 plane
 constexpr int STAGE_BYTES = A_BYTES + 2 * P_BYTES;   // 48 KB
-
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-
-struct DmaGemmArgs {
-    const float* A; const unsigned short* Whi; const unsigned short* Wlo; float* C;
-    int M, N, K, lda, ldc;
-    const float* bias; const float* dact_y; float slope;
-    // feed-ahead mode (FEED kernels only): the consumer of C is a persistent LSTM sweep that is ALREADY RUNNING
-    unsigned* queue;            // tile counter (zeroed by the host)
-    const unsigned* xcc_busy;   // [8] per-XCD count of sweep clusters, or nullptr (sweeper pass: any XCD)
-    unsigned* tiles_done;       // [2][mt_count]: finished column tiles per (direction half of N, row tile)
-    int mt_count, nt_count, order;   // order 0: forward-sweep consumption order, 1: backward-sweep order (mirrored)
-    // K in quarters (both kernels): the result is DEFINED as ((q0 + q1) + q2) + q3 with every quarter accumulated from
-    // zero, so that a tile whose quarters are computed by four workgroups in parallel (the first split_tiles tiles of a
-    // feed: a sweep is waiting for them, and one workgroup needs K/32 x 1.7 us for a tile) gives the same bits as a
-    // tile computed by one workgroup
-    int quarters;               // 1 or 4
-    int split_tiles;            // FEED: tiles (in queue order) whose quarters are separate work items
-    float* slabs;               // FEED: [split_tiles][4][64][512] partial accumulators
-    unsigned* arrive;           // FEED: [split_tiles] quarters finished (zeroed by the host)
-};
-
-__device__ __forceinline__ void dma16(const void* gsrc, void* lds_base) {
-    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
-                                     (void __attribute__((address_space(3)))*)lds_base, 16, 0, 0);
-}
-
-__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi_pk, unsigned& lo_pk) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
-    typedef __attribute__((ext_vector_type(2))) float f2;
-    const bf2 h = __builtin_convertvector((f2){x0, x1}, bf2);
-    hi_pk = __builtin_bit_cast(unsigned, h);
-    const float h0 = __uint_as_float(hi_pk << 16), h1 = __uint_as_float(hi_pk & 0xFFFF0000u);
-    const bf2 l = __builtin_convertvector((f2){x0 - h0, x1 - h1}, bf2);
-    lo_pk = __builtin_bit_cast(unsigned, l);
-}
-
-// XCD-aware tile order (same remap as gemm.hip): each XCD walks a contiguous run of the
-// n-fastest tile order, so the column tiles that share an A panel share an L2.
-__device__ __forceinline__ void swizzled_tile(int& bx, int& by) {
-    const unsigned gx = gridDim.x, gy = gridDim.y;
-    const unsigned nwg = gx * gy;
-    const unsigned L = blockIdx.x + gx * blockIdx.y;
-    const unsigned q = nwg / 8, r = nwg % 8;
-    const unsigned xcd = L % 8, i = L / 8;
-    const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-    bx = (int)(t % gx); by = (int)(t / gx);
-}
 
 // Fragments of one 16-deep k-step straight out of LDS: 2 row tiles x 2 chunks of fp32 A, 2 column tiles x (hi, lo)
 // of W.  Inline asm because hipcc puts s_waitcnt vmcnt(0) in front of any ds_read it can see after an LDS-DMA
@@ -303,26 +254,43 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_x3w_kernel(DmaGemmArgs g) {
                 for (int r = 0; r < 16; ++r) total[i][j][r] += acc[i][j][r];
     }
 
-    // epilogue: 32x32 accumulator layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue: 32x32 accumulator layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Branch-free: rows past M
+    // fall outside the buffer resource's range and are dropped by the hardware, and the optional leaky' factors of a
+    // 32 x 32 tile are loaded as ONE batch in front of its 16 stores.  (Round 1-2 had `if (m >= M) continue` plus a
+    // conditional dact load per element: hipcc then puts s_waitcnt vmcnt(0) in front of EVERY store -- each waits for the
+    // previous one's acknowledgement.  Measured round 3 on the 256 x 256 tile with DMA and MFMA switched off: the
+    // epilogue of the input projection took 160 of the kernel's 358 us.)
     const int cl = lane & 31, rq = lane >> 5;
-    __amdgpu_buffer_rsrc_t crs;
-    if (FEED) crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)((size_t)g.M * g.ldc * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(unsigned)((size_t)g.M * g.ldc * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dact_y ? g.dact_y : g.C), 0, (int)(unsigned)((size_t)g.M * g.ldc * 4), 0x00020000);
+    float bsum[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) bsum[j] = g.bias ? g.bias[n0 + wn * 64 + j * 32 + cl] : 0.f;
+    if (g.dact_y) {            // two straight-line loops: a merge point inside one would bring the per-tile s_waitcnt vmcnt(0) back
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + cl;
-            const float bsum = g.bias ? g.bias[n] : 0.f;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
-                if (m >= g.M) continue;
-                float v = total[i][j][r] + bsum;
-                if (g.dact_y) v *= (g.dact_y[(size_t)m * g.ldc + n] > 0.f ? 1.f : g.slope);
-                if (FEED) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crs, (unsigned)(((size_t)m * g.ldc + n) * 4), 0, 16);
-                else g.C[(size_t)m * g.ldc + n] = v;
+            for (int j = 0; j < 2; ++j) {
+                const unsigned o0 = (unsigned)(((size_t)(m0 + wm * 64 + i * 32 + 4 * rq) * g.ldc + n0 + wn * 64 + j * 32 + cl) * 4);
+                float f[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    f[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4), 0, 0)) > 0.f ? 1.f : g.slope;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((total[i][j][r] + bsum[j]) * f[r]), crs, o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4), 0, FEED ? 16 : 0);
             }
-        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned o0 = (unsigned)(((size_t)(m0 + wm * 64 + i * 32 + 4 * rq) * g.ldc + n0 + wn * 64 + j * 32 + cl) * 4);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(total[i][j][r] + bsum[j]), crs, o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4), 0, FEED ? 16 : 0);
+            }
+    }
     if (!FEED) return;
     // the tile's stores have reached memory (vmcnt(0) in every wave, then the barrier) before it is counted; the
     // barrier also retires every DMA of this tile before the next one reuses the stages
@@ -480,6 +448,7 @@ __global__ __launch_bounds__(THREADS) void gemm_x3w256_kernel(DmaGemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int diag = FEED ? 0 : g.quarters;      // plain launches carry a diagnostic code there (x3w_diag)
     RawA ra;
     RawB rb0, rb1;
 #pragma unroll
@@ -502,6 +471,7 @@ __global__ __launch_bounds__(THREADS) void gemm_x3w256_kernel(DmaGemmArgs g) {
         bf16x8_t bh[4], bl[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { bh[j] = __builtin_bit_cast(bf16x8_t, bcur.h[j]); bl[j] = __builtin_bit_cast(bf16x8_t, bcur.l[j]); }
+        if (FEED || !(diag & 2))
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -520,8 +490,9 @@ __global__ __launch_bounds__(THREADS) void gemm_x3w256_kernel(DmaGemmArgs g) {
         const unsigned sb = lds0 + (unsigned)((rel + 1) & 3) * STAGE_BYTES;
         read_a(ra, sb + offA[0], sb + offA[1], sb + offA[2], sb + offA[3]);
         read_b(bnxt, sb + offB[0], sb + offB[1], sb + offB[2], sb + offB[3]);
-        issue(kt + NST, rel & 3);
+        if (FEED || !(diag & 1)) issue(kt + NST, rel & 3);
         __builtin_amdgcn_sched_barrier(0);
+        if (FEED || !(diag & 2))
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             acc[3][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[3], bh[j], acc[3][j], 0, 0, 0);
@@ -575,26 +546,38 @@ __global__ __launch_bounds__(THREADS) void gemm_x3w256_kernel(DmaGemmArgs g) {
                 }
     }
 
-    // epilogue: 32x32 accumulator layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue (branch-free, see the 256 x 128 kernel): rows past M are dropped by the buffer resource's range check
     const int cl = lane & 31, rq = lane >> 5;
-    __amdgpu_buffer_rsrc_t crs;
-    if (FEED) crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)((size_t)g.M * g.ldc * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(unsigned)((size_t)g.M * g.ldc * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dact_y ? g.dact_y : g.C), 0, (int)(unsigned)((size_t)g.M * g.ldc * 4), 0x00020000);
+    float bsum[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) bsum[j] = g.bias ? g.bias[n0 + wn * 128 + j * 32 + cl] : 0.f;
+    if (g.dact_y) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 128 + j * 32 + cl;
-            const float bsum = g.bias ? g.bias[n] : 0.f;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
-                if (m >= g.M) continue;
-                float v = acc[i][j][r] + bsum;
-                if (g.dact_y) v *= (g.dact_y[(size_t)m * g.ldc + n] > 0.f ? 1.f : g.slope);
-                if (FEED) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crs, (unsigned)(((size_t)m * g.ldc + n) * 4), 0, 16);
-                else g.C[(size_t)m * g.ldc + n] = v;
+            for (int j = 0; j < 4; ++j) {
+                const unsigned o0 = (unsigned)(((size_t)(m0 + wm * 128 + i * 32 + 4 * rq) * g.ldc + n0 + wn * 128 + j * 32 + cl) * 4);
+                float f[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    f[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4), 0, 0)) > 0.f ? 1.f : g.slope;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[i][j][r] + bsum[j]) * f[r]), crs, o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4), 0, FEED ? 16 : 0);
             }
-        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned o0 = (unsigned)(((size_t)(m0 + wm * 128 + i * 32 + 4 * rq) * g.ldc + n0 + wn * 128 + j * 32 + cl) * 4);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r] + bsum[j]), crs, o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4), 0, FEED ? 16 : 0);
+            }
+    }
     if (!FEED) return;
     // the tile's stores have reached memory (vmcnt(0) in every wave, then the barrier) before it is counted; the
     // barrier also retires every DMA of this tile before the next one reuses the stages
@@ -605,6 +588,195 @@ __global__ __launch_bounds__(THREADS) void gemm_x3w256_kernel(DmaGemmArgs g) {
   }
 }
 }  // namespace w256
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradients dW = dY^T X (model.py:39-44 backward: dW_ih = dgates^T x, dW_hh = dgates^T h_prev) on the same
+// 256 x 256 tile: BOTH operands are fp32 activations stored k-major (rows = (t, b), the M / N index contiguous), K is
+// the long dimension (T*B = 32000) and the output is small, so the product is split over K into slabs that the
+// existing gemm_reduce_kernel sums in index order (deterministic).
+//   * stage = one 16-deep k-step: A[16][256] + B[16][256] fp32 = 32 KB, four stages; a DMA piece is one k-row of one
+//     operand (1 KB contiguous in HBM and in LDS: no swizzle needed);
+//   * an MFMA operand wants 8 k-values of ONE m per lane: ds_read2st64_b32 picks two of them (rows are 1 KB = 4 x 64
+//     dwords apart) per instruction, consecutive lanes read consecutive dwords -- conflict-free; which 8 k a lane holds
+//     (k = 8 (lane / 32) + e) is the same for both operands, which is all the MFMA needs;
+//   * both fragments are split into bf16 hi / lo in registers (this kernel is VALU-heavier than the NT one: 64 values
+//     per lane and k-step instead of 32).
+// ------------------------------------------------------------------------------------------------------------------
+namespace tn256 {
+constexpr int TM = 256, TN = 256, TK = 16, NST = 4, THREADS = 256;
+constexpr int OP_BYTES = TK * TM * 4;                // 16 KB per operand
+constexpr int STAGE_BYTES = 2 * OP_BYTES;            // 32 KB
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+
+struct RawOp { u32x2_t v[4][4]; };          // tile x k-pair: values k = 8 kg + 2 p, + 1
+
+__device__ __forceinline__ void read_op(RawOp& r, unsigned p0, unsigned p1, unsigned p2, unsigned p3) {
+    asm volatile("ds_read2st64_b32 %0, %16 offset0:0 offset1:4\n\t"
+                 "ds_read2st64_b32 %1, %16 offset0:8 offset1:12\n\t"
+                 "ds_read2st64_b32 %2, %16 offset0:16 offset1:20\n\t"
+                 "ds_read2st64_b32 %3, %16 offset0:24 offset1:28\n\t"
+                 "ds_read2st64_b32 %4, %17 offset0:0 offset1:4\n\t"
+                 "ds_read2st64_b32 %5, %17 offset0:8 offset1:12\n\t"
+                 "ds_read2st64_b32 %6, %17 offset0:16 offset1:20\n\t"
+                 "ds_read2st64_b32 %7, %17 offset0:24 offset1:28\n\t"
+                 "ds_read2st64_b32 %8, %18 offset0:0 offset1:4\n\t"
+                 "ds_read2st64_b32 %9, %18 offset0:8 offset1:12\n\t"
+                 "ds_read2st64_b32 %10, %18 offset0:16 offset1:20\n\t"
+                 "ds_read2st64_b32 %11, %18 offset0:24 offset1:28\n\t"
+                 "ds_read2st64_b32 %12, %19 offset0:0 offset1:4\n\t"
+                 "ds_read2st64_b32 %13, %19 offset0:8 offset1:12\n\t"
+                 "ds_read2st64_b32 %14, %19 offset0:16 offset1:20\n\t"
+                 "ds_read2st64_b32 %15, %19 offset0:24 offset1:28"
+                 : "=&v"(r.v[0][0]), "=&v"(r.v[0][1]), "=&v"(r.v[0][2]), "=&v"(r.v[0][3]),
+                   "=&v"(r.v[1][0]), "=&v"(r.v[1][1]), "=&v"(r.v[1][2]), "=&v"(r.v[1][3]),
+                   "=&v"(r.v[2][0]), "=&v"(r.v[2][1]), "=&v"(r.v[2][2]), "=&v"(r.v[2][3]),
+                   "=&v"(r.v[3][0]), "=&v"(r.v[3][1]), "=&v"(r.v[3][2]), "=&v"(r.v[3][3])
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                 : "memory");
+}
+__device__ __forceinline__ void wait_ops(RawOp& a, RawOp& b) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a.v[0][0]), "+v"(a.v[0][1]), "+v"(a.v[0][2]), "+v"(a.v[0][3]),
+                   "+v"(a.v[1][0]), "+v"(a.v[1][1]), "+v"(a.v[1][2]), "+v"(a.v[1][3]),
+                   "+v"(a.v[2][0]), "+v"(a.v[2][1]), "+v"(a.v[2][2]), "+v"(a.v[2][3]),
+                   "+v"(a.v[3][0]), "+v"(a.v[3][1]), "+v"(a.v[3][2]), "+v"(a.v[3][3])
+                 :: "memory");
+    asm volatile(""
+                 : "+v"(b.v[0][0]), "+v"(b.v[0][1]), "+v"(b.v[0][2]), "+v"(b.v[0][3]),
+                   "+v"(b.v[1][0]), "+v"(b.v[1][1]), "+v"(b.v[1][2]), "+v"(b.v[1][3]),
+                   "+v"(b.v[2][0]), "+v"(b.v[2][1]), "+v"(b.v[2][2]), "+v"(b.v[2][3]),
+                   "+v"(b.v[3][0]), "+v"(b.v[3][1]), "+v"(b.v[3][2]), "+v"(b.v[3][3])
+                 :: "memory");
+}
+__device__ __forceinline__ void split_tile(const u32x2_t (&v)[4], bf16x8_t& hi, bf16x8_t& lo) {
+    u32x4_t h, l;
+    unsigned a, b;
+    split2(__uint_as_float(v[0].x), __uint_as_float(v[0].y), a, b); h.x = a; l.x = b;
+    split2(__uint_as_float(v[1].x), __uint_as_float(v[1].y), a, b); h.y = a; l.y = b;
+    split2(__uint_as_float(v[2].x), __uint_as_float(v[2].y), a, b); h.z = a; l.z = b;
+    split2(__uint_as_float(v[3].x), __uint_as_float(v[3].y), a, b); h.w = a; l.w = b;
+    hi = __builtin_bit_cast(bf16x8_t, h); lo = __builtin_bit_cast(bf16x8_t, l);
+}
+
+__global__ __launch_bounds__(THREADS) void gemm_tn256_kernel(PgasrTn256Args g) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    if (g.queue && g.xcc_busy) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;
+        if (__hip_atomic_load(g.xcc_busy + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    }
+    const int tx = g.N / TN, ty = g.M / TM;
+    const unsigned nitems = (unsigned)(tx * ty) * (unsigned)(g.batch * g.splitk);
+  for (;;) {
+    unsigned item;
+    if (g.queue) {
+        unsigned* mailbox = reinterpret_cast<unsigned*>(smem + NST * STAGE_BYTES);
+        if (tid == 0) *mailbox = __hip_atomic_fetch_add(g.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        item = *mailbox;
+        __syncthreads();
+    } else {
+        item = blockIdx.x;
+    }
+    if (item >= nitems) return;
+    // items of one K-slab are adjacent (they run at the same time and share the slab's rows in L2 / MALL)
+    const int z = (int)(item / (unsigned)(tx * ty)), t2 = (int)(item % (unsigned)(tx * ty));
+    const int tbx = t2 % tx, tby = t2 / tx;
+    const int bidx = z / g.splitk, sidx = z % g.splitk;
+    const int k_beg = sidx * g.kper, k_end = (k_beg + g.kper < g.K) ? k_beg + g.kper : g.K;
+    const int nk = k_end > k_beg ? (k_end - k_beg) / TK : 0;        // even (K, kper multiples of 32)
+    const int m0 = tby * TM, n0 = tbx * TN;
+    const float* Ab = g.A + (size_t)bidx * g.sA + m0 + 4 * lane;
+    const float* Bb = g.B + (size_t)bidx * g.sB + n0 + 4 * lane;
+
+    auto issue = [&](int kt, int stage) {      // ALWAYS 8 wave-instructions: wave w moves k-rows 4j + w of both operands
+        int k0 = k_beg + (kt < nk ? kt : (nk > 0 ? nk - 1 : 0)) * TK;
+        if (k0 + TK > g.K) k0 = g.K - TK;
+        unsigned char* sa = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16(Ab + (size_t)(k0 + 4 * j + w) * g.lda, sa + (4 * j + w) * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16(Bb + (size_t)(k0 + 4 * j + w) * g.ldb, sa + OP_BYTES + (4 * j + w) * 1024);
+    };
+
+    const int fr = lane & 31, fh = lane >> 5;
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        offA[i] = (unsigned)(fh * 8 * 1024 + (wm * 128 + i * 32 + fr) * 4);
+        offB[i] = (unsigned)(OP_BYTES + fh * 8 * 1024 + (wn * 128 + i * 32 + fr) * 4);
+    }
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    RawOp ra, rb;
+#pragma unroll
+    for (int s = 0; s < NST; ++s) issue(s, s);
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_op(ra, lds0 + offA[0], lds0 + offA[1], lds0 + offA[2], lds0 + offA[3]);
+    read_op(rb, lds0 + offB[0], lds0 + offB[1], lds0 + offB[2], lds0 + offB[3]);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_ops(ra, rb);
+        bf16x8_t ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { split_tile(ra.v[i], ah[i], al[i]); split_tile(rb.v[i], bh[i], bl[i]); }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned sb = lds0 + (unsigned)((kt + 1) & 3) * STAGE_BYTES;
+        read_op(ra, sb + offA[0], sb + offA[1], sb + offA[2], sb + offA[3]);
+        read_op(rb, sb + offB[0], sb + offB[1], sb + offB[2], sb + offB[3]);
+        issue(kt + NST, kt & 3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[3][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[3], bh[j], acc[3][j], 0, 0, 0);
+            acc[3][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[3], bl[j], acc[3][j], 0, 0, 0);
+            acc[3][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[3], bh[j], acc[3][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    wait_ops(ra, rb);
+
+    // raw alpha * acc into this item's slab: 32x32 accumulator layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* slab = g.partial + (size_t)z * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 128 + j * 32 + fr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                slab[(size_t)m * g.N + n] = g.alpha * acc[i][j][r];
+            }
+        }
+    if (!g.queue) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every DMA of this item has retired before the stages are reused
+    __syncthreads();
+  }
+}
+}  // namespace tn256
 
 // fp32 (rows x cols, leading dim ld) -> dense bf16 hi / lo planes; transpose: planes are (cols x rows)
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int rows, int cols, int ld,
@@ -633,10 +805,24 @@ extern "C" int pgasr_split_bf16_planes(const float* src, int rows, int cols, int
     return PGASR_OK;
 }
 
-// PGASR_X3W_TILE=128 in the environment keeps the round-1 256 x 128 kernel (A/B measurements only)
-static bool x3w_force_128() {
-    static const bool v = [] { const char* e = getenv("PGASR_X3W_TILE"); return e && e[0] == '1' && e[1] == '2' && e[2] == '8'; }();
-    return v;
+// The 256 x 256 kernel is opt-in (PGASR_X3W_TILE=256) until it beats the 256 x 128 one on the path's shapes: first
+// measurement (round 3, one box): input projection 336 against 283 us, input gradient 218 against 223 us.
+// PGASR_X3W_TILE selects the x3w kernel (read at every call: tests and A/B scripts switch it inside one process):
+// "128": 256 x 128 (8 waves x 64 x 64), "256": 256 x 256 / 4 waves (w256 below), "c": 256 x 256 / 8 waves with the
+// cooperative A split (gemm_c256.hip).  Unset: plain launches take "c" (round 3, one box, the path's two shapes: 227 / 225 us
+// against 260 / 269 for "128" and 237 / 229 for "256"); FEED launches keep "128": what a fed sweep waits for is its FIRST
+// row tiles, and the smaller tile delivers them sooner (train step 8.55 ms with "128" feeds against 8.69 with "c" feeds,
+// backward sweeps 1.25 / 1.27 against 1.32 / 1.33 ms).
+static int x3w_tile_mode(bool feed) {
+    const char* e = getenv("PGASR_X3W_TILE");
+    if (!e || !e[0]) return feed ? 0 : 2;
+    if (e[0] == 'c') return 2;
+    if (e[0] == '2' && e[1] == '5' && e[2] == '6') return 1;
+    return 0;
+}
+static int x3w_diag() {      // diagnostic variants of the 256 x 256 / 4-wave kernel (results invalid): bit 0 = no DMA in the k-loop, bit 1 = no MFMA
+    const char* e = getenv("PGASR_X3W_DIAG");
+    return e ? atoi(e) : 0;
 }
 static int x3w_quarters(int K) { return (K >= 1024 && K % (4 * TK) == 0) ? 4 : 1; }   // a quarter of >= 8 k-tiles (K = 512 in quarters: step +0.05 ms)
 constexpr int FEED_SPLIT_MAX = 64;       // split tiles per feed: 4 x 64 slabs of 128 KB = 32 MB of workspace
@@ -645,7 +831,7 @@ constexpr int FEED_SPLIT_MAX = 64;       // split tiles per feed: 4 x 64 slabs o
 // N / 2 / 256 on the 256 x 256 tile, N / 2 / 128 on the 256 x 128 one; 0: not a feedable width.
 extern "C" int pgasr_gemm_x3w_feed_col_tiles(int N) {
     if (N <= 0 || N % (2 * TN)) return 0;
-    if (N % (2 * w256::TN) == 0 && !x3w_force_128()) return N / (2 * w256::TN);
+    if (N % (2 * w256::TN) == 0 && x3w_tile_mode(true) != 0) return N / (2 * w256::TN);
     return N / (2 * TN);
 }
 
@@ -659,11 +845,16 @@ extern "C" int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, 
         return PGASR_ERR_UNSUPPORTED;
     const unsigned gy = (unsigned)((M + TM - 1) / TM);
     if (gy > 65535u) return PGASR_ERR_UNSUPPORTED;
-    if (N % w256::TN == 0 && !x3w_force_128()) {     // the 256 x 256 tile (one accumulation chain over K per tile)
+    if ((size_t)M * ldc * 4 >= ((size_t)1 << 32)) return PGASR_ERR_UNSUPPORTED;      // buffer-addressed epilogue (callers fall back to pgasr_gemm_f32)
+    if (N % 256 == 0 && x3w_tile_mode(false) == 2 && (size_t)M * lda * 4 < ((size_t)1 << 32)) {
+        PgasrX3cArgs a{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, dact_y, slope, 0, nullptr, nullptr, nullptr, 0, 0, 0, x3w_diag(), 0, nullptr, nullptr};
+        return pgasr_internal_x3c_launch(a, (hipStream_t)stream);
+    }
+    if (N % w256::TN == 0 && x3w_tile_mode(false) == 1) {     // the 256 x 256 / 4-wave tile (one accumulation chain over K per tile)
         const size_t lds2 = (size_t)w256::NST * w256::STAGE_BYTES;
         if (hipFuncSetAttribute((const void*)w256::gemm_x3w256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
             return PGASR_ERR_LAUNCH;
-        DmaGemmArgs g2{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, dact_y, slope, nullptr, nullptr, nullptr, 0, 0, 0, 1, 0, nullptr, nullptr};
+        DmaGemmArgs g2{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, dact_y, slope, nullptr, nullptr, nullptr, 0, 0, 0, x3w_diag(), 0, nullptr, nullptr};
         PGASR_LAUNCH_KERNEL(w256::gemm_x3w256_kernel<false>, dim3((unsigned)(N / w256::TN), gy), dim3(w256::THREADS), lds2, (hipStream_t)stream, g2);
         PGASR_CHECK_LAUNCH();
         return PGASR_OK;
@@ -698,6 +889,22 @@ extern "C" int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int 
         return PGASR_ERR_UNSUPPORTED;
     if ((size_t)M * ldc * 4 >= ((size_t)1 << 31)) return PGASR_ERR_UNSUPPORTED;      // buffer-addressed stores
     hipStream_t st = (hipStream_t)stream;
+    if (pgasr_gemm_x3w_feed_col_tiles(N) == N / (2 * w256::TN) && x3w_tile_mode(true) == 2 && (size_t)M * lda * 4 < ((size_t)1 << 32)) {
+        const int mt2 = (M + 255) / 256, nt2 = N / 256;
+        if (hipMemsetAsync(workspace, 0, 1024, st) != hipSuccess) return PGASR_ERR_LAUNCH;
+        const int quarters2 = x3w_quarters(K);
+        int split2 = 0;
+        if (quarters2 == 4) {
+            const size_t room = (workspace_bytes - 1024) / ((size_t)4 * pgasr_internal_x3c_slab_bytes());
+            split2 = 16 * nt2;
+            if (split2 > FEED_SPLIT_MAX) split2 = FEED_SPLIT_MAX;
+            if ((size_t)split2 > room) split2 = (int)room;
+            if (split2 > mt2 * nt2) split2 = mt2 * nt2;
+        }
+        PgasrX3cArgs a{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, nullptr, 0.f, 1, (unsigned*)workspace, xcc_busy, tiles_done, mt2, nt2, order,
+                       quarters2, split2, (float*)((char*)workspace + 1024), (unsigned*)workspace + 64};
+        return pgasr_internal_x3c_launch(a, st);
+    }
     if (pgasr_gemm_x3w_feed_col_tiles(N) == N / (2 * w256::TN)) {
         // 256 x 256 tiles: the same queue, counters and quarter protocol, slabs of 256 KB
         const int mt2 = (M + w256::TM - 1) / w256::TM, nt2 = N / w256::TN;
@@ -745,6 +952,38 @@ extern "C" int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int 
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) g.xcc_busy = nullptr;
         PGASR_LAUNCH_KERNEL(gemm_x3w_kernel<true>, dim3(256), dim3(DMA_THREADS), lds, st, g);
+        PGASR_CHECK_LAUNCH();
+    }
+    return PGASR_OK;
+}
+
+bool pgasr_internal_tn256_ok(const PgasrTn256Args& a) {
+    // opt-in (PGASR_TN_TILE=256, read at every call) until it wins where it is used: measured round 3 on the dW_ih shape
+    // (2048 x 512 x 32000), whole chip: split-K 16 (256 items) 232 us against 275 us for the 128 x 128 kernel at its best
+    // split (8) -- but with the 128 items that fit beside a sweep (split-K 8) 415 us against 275.
+    const char* e = getenv("PGASR_TN_TILE");
+    if (!(e && e[0] == '2' && e[1] == '5' && e[2] == '6')) return false;
+    if (!a.A || !a.B || !a.partial || a.M <= 0 || a.N <= 0 || a.K < 32 || a.batch <= 0 || a.splitk <= 0) return false;
+    if ((a.M % tn256::TM) || (a.N % tn256::TN) || (a.K % 32) || (a.kper % 32) || (a.lda & 3) || (a.ldb & 3)) return false;
+    if ((a.sA & 3) || (a.sB & 3) || (((size_t)a.A) & 15) || (((size_t)a.B) & 15)) return false;
+    if ((long long)(a.splitk - 1) * a.kper >= a.K) return false;        // no empty slab
+    return true;
+}
+
+int pgasr_internal_tn256_launch(PgasrTn256Args a, int masked_then_unmasked, hipStream_t st) {
+    const size_t lds = (size_t)tn256::NST * tn256::STAGE_BYTES + 16;
+    if (hipFuncSetAttribute((const void*)tn256::gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PGASR_ERR_LAUNCH;
+    const unsigned nitems = (unsigned)((a.N / tn256::TN) * (a.M / tn256::TM)) * (unsigned)(a.batch * a.splitk);
+    if (!a.queue) {
+        PGASR_LAUNCH_KERNEL(tn256::gemm_tn256_kernel, dim3(nitems), dim3(tn256::THREADS), lds, st, a);
+        PGASR_CHECK_LAUNCH();
+        return PGASR_OK;
+    }
+    const unsigned* busy = a.xcc_busy;
+    for (int pass = 0; pass < (masked_then_unmasked ? 2 : 1); ++pass) {
+        a.xcc_busy = (pass == 0) ? busy : nullptr;
+        PGASR_LAUNCH_KERNEL(tn256::gemm_tn256_kernel, dim3(256), dim3(tn256::THREADS), lds, st, a);
         PGASR_CHECK_LAUNCH();
     }
     return PGASR_OK;

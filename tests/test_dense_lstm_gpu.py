@@ -52,10 +52,12 @@ def test_gemm_layouts(tA, tB, M, N, K, precision, tol):
     (2000, 2048, 512, False, True),     # the input projection's K and N
     (1031, 512, 352, True, True),       # 22 k-steps: the ring wraps five times, odd number of pairs
 ])
-def test_gemm_x3w_lds_dma(M, N, K, with_bias, with_dact):
-    """pgasr_gemm_x3w_f32 (LDS-DMA tiles, pre-split weight planes) against fp64, and against the
-    register-staged bf16x3 kernel it replaces on the big shapes."""
+@pytest.mark.parametrize("tile", ["128", "256", "c"])
+def test_gemm_x3w_lds_dma(M, N, K, with_bias, with_dact, tile, monkeypatch):
+    """pgasr_gemm_x3w_f32 (LDS-DMA tiles, pre-split weight planes) against fp64, in each of its three tile structures
+    (PGASR_X3W_TILE, read by the library at every call; N % 256 != 0 always takes the 256 x 128 kernel)."""
     from policy_gradient_asr_amd import hipops
+    monkeypatch.setenv("PGASR_X3W_TILE", tile)
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g)
     W = torch.randn(N, K, generator=g) * 0.1
@@ -100,6 +102,43 @@ def test_gemm_queue_mode_is_placement_independent(busy_mask):
     assert torch.equal(got, want)
     ref = base.double().cpu() + A.double().cpu().t() @ B.double().cpu()
     assert rel_err(got.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,splitk,batch", [
+    (256, 256, 64, 2, 1),            # one tile, one pair of k-steps per slab (fewer than the ring's four stages)
+    (1024, 512, 3200, 4, 1),         # dW_ih-like; slabs of 800 -> kper 800 = 25 x 32
+    (512, 256, 2016, 5, 2),          # two batches (dW_hh's two directions), a shorter last slab, 63 pairs
+    (2048, 512, 8000, 8, 1),         # eight row tiles x two column tiles x eight slabs = 128 items
+])
+def test_gemm_tn_256_tile_weight_gradient_shapes(M, N, K, splitk, batch, monkeypatch):
+    """TN products with both operands k-major (dW = dY^T X, model.py:39-44 backward) on the 256 x 256 LDS-DMA tile of
+    gemm_dma.hip (taken by pgasr_gemm_f32 for M, N % 256 == 0, K % 32 == 0, split-K slabs of multiples of 32): against
+    fp64, with the reduce epilogue (accumulate into C), with batch strides, plain and in queue mode under every kind of
+    XCD mask -- bit-identical whichever workgroup computes which item."""
+    from policy_gradient_asr_amd import hipops
+    monkeypatch.setenv("PGASR_TN_TILE", "256")          # opt-in kernel (read by the library at every call)
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(batch, K, M, generator=g).to(DEV)
+    B = torch.randn(batch, K, N, generator=g).to(DEV)
+    base = torch.randn(batch, M, N, generator=g).to(DEV)
+    ref = base.double().cpu() + torch.einsum("bkm,bkn->bmn", A.double().cpu(), B.double().cpu())
+    outs = []
+    for mask in (None, 0x00, 0x0F, 0xFE, 0xFF):
+        busy = None if mask is None else torch.tensor([(mask >> i) & 1 for i in range(8)], dtype=torch.int32, device=DEV)
+        got = base.clone()
+        hipops.gemm(A, B, got, M, N, K, transA=True, splitk=splitk, accumulate=True, precision=1, batch=batch,
+                    strideA=K * M, strideB=K * N, strideC=M * N, xcc_busy=None if busy is None else busy.data_ptr())
+        torch.cuda.synchronize()
+        outs.append(got)
+    assert rel_err(outs[0].cpu(), ref) < 1e-5
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    # sum_batches: the two batches' slabs summed into ONE output
+    if batch > 1:
+        one = torch.zeros(M, N, device=DEV)
+        hipops.gemm(A, B, one, M, N, K, transA=True, splitk=splitk, precision=1, batch=batch, sum_batches=True,
+                    strideA=K * M, strideB=K * N, strideC=0)
+        assert rel_err(one.cpu(), (ref - base.double().cpu()).sum(0)) < 1e-5
 
 
 def test_instnorm_affine_fwd_bwd():
