@@ -197,12 +197,20 @@ int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, const unsig
  * zero tiles_done -> pgasr_lstm_layer_fwd_fed (stream S) -> pgasr_stream_gate + this call (another stream that
  * waits for the zeroing).  order 0: rows in the order a forward sweep consumes them; 1: a backward sweep's (the
  * product is then the input gradient of the layer above, feeding pgasr_lstm_layer_bwd_fed).  Needs N % 256 == 0 on top of pgasr_gemm_x3w_f32's conditions and M*ldc*4 < 2^31. */
+/* phase 0: the whole feed in one call (queue zeroed here, two persistent launches).  phase 1 (HEAD) + phase 2 (REST) split it:
+ * phase 1 zeroes the queue and computes the first head_groups tile groups -- pgasr_gemm_x3w_feed_head_items(N, K, head_groups)
+ * work items, one per workgroup, no XCD mask -- and is meant for the SWEEP'S OWN stream, in front of the sweep launch, so
+ * that the rows of the sweep's first steps are in memory when it starts (they are what a fed sweep otherwise waits ~50-70 us
+ * for: stream gate + launch + first tiles); phase 2, on the feeding stream and ordered behind phase 1, continues the SAME
+ * queue (same workspace, not zeroed again) with the persistent launches.  The decomposition -- and so the bits -- is the
+ * same as phase 0's.  head_items == 0: no head for this shape (use phase 0). */
 size_t pgasr_gemm_x3w_feed_workspace_bytes(void);
 int pgasr_gemm_x3w_feed_col_tiles(int N);
+int pgasr_gemm_x3w_feed_head_items(int N, int K, int groups);
 int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
                             const unsigned short* Wlo, float* C, int ldc, const float* bias,
-                            const unsigned* xcc_busy, unsigned* tiles_done, int order, void* workspace,
-                            size_t workspace_bytes, void* stream);
+                            const unsigned* xcc_busy, unsigned* tiles_done, int order, int phase, int head_groups,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 size_t pgasr_colsum_workspace_bytes(int rows, int cols);
 int pgasr_colsum_f32(const float* X, int rows, int cols, int ld, float* out, float* out2, int accumulate,

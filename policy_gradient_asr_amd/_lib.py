@@ -57,8 +57,9 @@ SIGNATURES = {
                                      c_f32p, c_f32p, C.c_float, c_ptr]),
     "pgasr_gemm_x3w_feed_workspace_bytes": (C.c_size_t, []),
     "pgasr_gemm_x3w_feed_col_tiles": (C.c_int, [C.c_int]),
+    "pgasr_gemm_x3w_feed_head_items": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pgasr_gemm_x3w_feed_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_ptr, c_ptr, c_f32p, C.c_int,
-                                          c_f32p, c_ptr, c_ptr, C.c_int, c_ptr, C.c_size_t, c_ptr]),
+                                          c_f32p, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, C.c_size_t, c_ptr]),
     "pgasr_feat_frames": (C.c_int, [c_f32p, c_i32p, c_i32p, C.c_int, C.c_longlong, C.c_int, c_f32p, c_ptr]),
     "pgasr_feat_power": (C.c_int, [c_f32p, C.c_longlong, c_f32p, c_ptr]),
     "pgasr_feat_db": (C.c_int, [c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_float, c_ptr]),

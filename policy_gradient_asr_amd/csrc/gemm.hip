@@ -38,7 +38,94 @@ struct GemmArgs {
     unsigned* queue;           // queue mode (else NULL): global tile counter, zeroed before the launch
     const unsigned* xcc_busy;  // queue mode: [8] words; a workgroup running on XCD i (HW_REG_XCC_ID) with busy[i] != 0 takes no tile
     int tx, ty, tz;            // queue mode: tile counts
+    int wide;                  // some byte offset of the output needs more than 32 bits: the epilogue keeps 64-bit addressing
 };
+
+// Epilogue of both tile kernels (32x32 accumulator layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).
+// Branch-free per element: every store and load goes through a buffer resource whose range check drops what lies past
+// the output (rows >= M; columns >= N and dead workgroups get the out-of-range offset 0xFFFFFFFF), and the optional
+// operands of a 32 x 32 tile (leaky' mask, accumulate target) are loaded as one batch in front of its 16 stores.
+// Rounds 1-2 had `if (m >= M) continue` and conditional loads per element; hipcc then puts s_waitcnt vmcnt(0) in front
+// of EVERY store, i.e. each store waits for the previous one's acknowledgement (found in round 3 with the k-loop of an
+// LDS-DMA kernel switched off: the epilogue of the input projection took 160 of 358 us).  Needs every byte offset
+// below 2^32 (checked on the host: GemmArgs::wide == 0); otherwise the old per-element form runs.
+__device__ __forceinline__ void store_tiles_fast(const GemmArgs& g, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
+                                                 int lane, int z, int bidx, bool live) {
+    const int cl = lane & 31, rq = lane >> 5;
+    if (g.partial) {
+        float* slab = g.partial + (size_t)z * g.M * g.N;
+        __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)(unsigned)((size_t)g.M * g.N * 4), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + cl;
+                const bool ok = live && n < g.N;
+                const unsigned o0 = (unsigned)(((size_t)(m0 + wm * 64 + i * 32 + 4 * rq) * g.N + n) * 4);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(g.alpha * acc[i][j][r]), prs,
+                                                          ok ? o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.N * 4) : 0xFFFFFFFFu, 0, 0);
+            }
+        return;
+    }
+    float* Cb = g.C + (size_t)bidx * g.sC;
+    const unsigned cbytes = (unsigned)(((size_t)(g.M - 1) * g.ldc + g.N) * 4);
+    __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(Cb, 0, (int)cbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dact_y ? g.dact_y + (size_t)bidx * g.sC : Cb), 0, (int)cbytes, 0x00020000);
+    float bsum[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + cl;
+        bsum[j] = 0.f;
+        if (n < g.N) {
+            if (g.bias) bsum[j] += g.bias[n];
+            if (g.bias2) bsum[j] += g.bias2[n];
+        }
+    }
+    const bool lk = g.act == 1;
+    if (!g.dact_y && !g.accumulate) {             // straight-line stores
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + cl;
+                const bool ok = live && n < g.N;
+                const unsigned o0 = (unsigned)(((size_t)(m0 + wm * 64 + i * 32 + 4 * rq) * g.ldc + n) * 4);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = g.alpha * acc[i][j][r] + bsum[j];
+                    v = (lk && !(v > 0.f)) ? v * g.slope : v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crs, ok ? o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4) : 0xFFFFFFFFu, 0, 0);
+                }
+            }
+        return;
+    }
+    const bool hd = g.dact_y != nullptr, ha = g.accumulate != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + cl;
+            const bool ok = live && n < g.N;
+            const unsigned o0 = (unsigned)(((size_t)(m0 + wm * 64 + i * 32 + 4 * rq) * g.ldc + n) * 4);
+            float f[16], c0[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {       // out-of-range loads return 0 (harmless: their stores are dropped as well)
+                const unsigned o = ok ? o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4) : 0xFFFFFFFFu;
+                f[r] = hd ? (__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, o, 0, 0)) > 0.f ? 1.f : g.slope) : 1.f;
+                c0[r] = ha ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crs, o, 0, 0)) : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned o = ok ? o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4) : 0xFFFFFFFFu;
+                float v = g.alpha * acc[i][j][r] + bsum[j];
+                v = (lk && !(v > 0.f)) ? v * g.slope : v;
+                v = v * f[r] + c0[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crs, o, 0, 0);
+            }
+        }
+}
 
 // Load an 8-float strip of a tile operand.  KCONTIG: the operand is stored with k contiguous
 // (row-major MxK A, or NxK "B^T"); otherwise the M/N index is contiguous.
@@ -192,6 +279,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(GemmArgs g) {
     }
 
     // epilogue
+    if (!g.wide) { store_tiles_fast(g, acc, m0, n0, wm, wn, lane, z, bidx, true); return; }
     const int cl = lane & 31, rq = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -468,6 +556,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(GemmArgs g
 #undef XSTORE
 
     // epilogue (identical to the fp32 kernel: the 32x32 accumulator layout is dtype independent)
+    if (!g.wide) { store_tiles_fast(g, acc, m0, n0, wm, wn, lane, z, bidx, live); return; }
     const int cl = lane & 31, rq = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -692,6 +781,7 @@ extern "C" int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float
     g.kper = kper;
     g.alpha = alpha; g.bias = bias; g.bias2 = bias2; g.act = act; g.slope = slope; g.accumulate = accumulate;
     g.dact_y = dact_y; g.norm_operand = norm_operand; g.shift = shift; g.scale = scale; g.partial = nullptr;
+    g.wide = (((size_t)(M - 1) * ldc + N) * 4 >= ((size_t)1 << 32) || (size_t)M * N * 4 >= ((size_t)1 << 32)) ? 1 : 0;
     return gemm_launch(g, transA, transB, sum_batches, precision, xcc_busy, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

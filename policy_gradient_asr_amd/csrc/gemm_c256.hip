@@ -321,6 +321,176 @@ __global__ __launch_bounds__(THREADS) void gemm_x3c_kernel(DmaGemmArgs g) {
 }  // namespace c256
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradients dW = dY^T X (model.py:39-44 backward: dW_ih = dgates^T x, dW_hh = dgates^T h_prev) on the same
+// 256 x 256 / 8-wave structure.  BOTH operands are fp32 activations stored k-major (rows = (t, b); the M / N index is
+// contiguous), K = T*B is long and the output small, so the product is split over K into slabs that gemm.hip's
+// gemm_reduce_kernel sums in index order (deterministic) -- this kernel is reached through pgasr_gemm_f32.
+//   * no LDS-DMA: a thread loads 8 x 16 B per 32-deep step (a wave instruction = one 1-KB k-row, fully coalesced),
+//     splits the 32 values into bf16 hi / lo and writes both planes with 8-byte stores into a k-major LDS image
+//     [k][256 + 32 pad] (pitch 576 B = 64 mod 256: the four k-rows of a transposing read's two 4 x 16 blocks cover the
+//     64 banks once) -- the split happens once per workgroup, not once per wave as in gemm.hip's 128 x 128 kernel;
+//   * MFMA fragments (8 k of one m) come out of ds_read_b64_tr_b16, as in gemm.hip's TN kernel;
+//   * two LDS buffers of 72 KB, one raw s_barrier per step; the loads of step t + 2 are issued as soon as the registers
+//     of step t + 1 have been converted, i.e. a full step ahead of their use, and are NOT drained by the barrier
+//     (a plain __syncthreads() would wait for them);
+//   * the two waves of a SIMD are half a step out of phase (waves 4-7 multiply the first 16-deep half before they
+//     convert), so one wave's VALU / LDS-write phase sits beside its partner's MFMA phase;
+//   * 256 x 256 tiles halve the operand bytes per flop of the 128 x 128 kernel (16 x 1000 steps x 64 KB = 1 GB against
+//     2 GB on the dW_ih shape).
+// Requirements: pgasr_internal_tn256_ok.
+// ------------------------------------------------------------------------------------------------------------------
+namespace t256 {
+constexpr int TM = 256, TN = 256, TK = 32, THREADS = 512;
+constexpr int PITCH = 288;                        // halfs per k-row of a plane image (576 B)
+constexpr int PLANE_HALFS = TK * PITCH;           // 9216 halfs = 18 KB
+constexpr int BUF_HALFS = 4 * PLANE_HALFS;        // A hi | A lo | B hi | B lo = 72 KB
+constexpr int LDS_BYTES = 2 * BUF_HALFS * 2;      // 144 KB
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ bf16x8_t tr_frag(const unsigned short* p) {
+    typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_ptr;
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * PITCH));
+    return __builtin_bit_cast(bf16x8_t, (s16x8_t){a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w});
+}
+
+__global__ __launch_bounds__(THREADS) void gemm_t256_kernel(PgasrTn256Args g) {
+    extern __shared__ __attribute__((aligned(128))) unsigned short S[];      // the ONLY LDS object: [buffer][A hi, A lo, B hi, B lo][k][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 2, wn = w & 3;
+    if (g.queue && g.xcc_busy) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;
+        if (__hip_atomic_load(g.xcc_busy + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    }
+    const int tx = g.N / TN, ty = g.M / TM;
+    const unsigned nitems = (unsigned)(tx * ty) * (unsigned)(g.batch * g.splitk);
+    // lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3 of the group's 4 x 16 block; groups 0,1 take
+    // columns 0-15 / 16-31 of k 0-7, groups 2,3 the same columns of k 8-15 (= the 32x32x16 operand map)
+    const int tro = (8 * (lane >> 5) + ((lane & 15) >> 2)) * PITCH + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  for (;;) {
+    unsigned item;
+    if (g.queue) {
+        unsigned* mailbox = reinterpret_cast<unsigned*>(S);       // the buffers are idle between two items
+        if (tid == 0) *mailbox = __hip_atomic_fetch_add(g.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        item = *mailbox;
+        __syncthreads();
+    } else {
+        item = blockIdx.x;
+    }
+    if (item >= nitems) return;
+    // items of one K-slab are adjacent: they run at the same time and share the slab's rows in L2 / MALL
+    const int z = (int)(item / (unsigned)(tx * ty)), t2 = (int)(item % (unsigned)(tx * ty));
+    const int tbx = t2 % tx, tby = t2 / tx;
+    const int bidx = z / g.splitk, sidx = z % g.splitk;
+    const int k_beg = sidx * g.kper, k_end = (k_beg + g.kper < g.K) ? k_beg + g.kper : g.K;
+    const int nk = (k_end - k_beg) / TK;               // >= 1 (pgasr_internal_tn256_ok: no empty slab)
+    const int m0 = tby * TM, n0 = tbx * TN;
+    // wave w loads k-rows 4 w + j (j = 0..3) of both operands: one 1-KB row per wave instruction
+    const float* Ab = g.A + (size_t)bidx * g.sA + (size_t)(k_beg + 4 * w) * g.lda + m0 + 4 * lane;
+    const float* Bb = g.B + (size_t)bidx * g.sB + (size_t)(k_beg + 4 * w) * g.ldb + n0 + 4 * lane;
+    f32x4_t ra[4], rb[4];
+    auto load = [&](int kt) {
+        const int kc = kt < nk ? kt : nk - 1;          // past the slab: reload the last step (never converted)
+        const float* pa = Ab + (size_t)kc * TK * g.lda;
+        const float* pb = Bb + (size_t)kc * TK * g.ldb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ra[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(pa + (size_t)j * g.lda));
+            rb[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(pb + (size_t)j * g.ldb));
+        }
+    };
+    auto convert = [&](int buf) {
+        unsigned short* base = S + buf * BUF_HALFS + (4 * w) * PITCH + 4 * lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned h0, l0, h1, l1;
+            split2(ra[j].x, ra[j].y, h0, l0); split2(ra[j].z, ra[j].w, h1, l1);
+            *reinterpret_cast<u32x2_t*>(base + j * PITCH) = (u32x2_t){h0, h1};
+            *reinterpret_cast<u32x2_t*>(base + PLANE_HALFS + j * PITCH) = (u32x2_t){l0, l1};
+            split2(rb[j].x, rb[j].y, h0, l0); split2(rb[j].z, rb[j].w, h1, l1);
+            *reinterpret_cast<u32x2_t*>(base + 2 * PLANE_HALFS + j * PITCH) = (u32x2_t){h0, h1};
+            *reinterpret_cast<u32x2_t*>(base + 3 * PLANE_HALFS + j * PITCH) = (u32x2_t){l0, l1};
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto multiply = [&](int buf, int ks) {             // one 16-deep half of a step: 24 MFMAs
+        const unsigned short* img = S + buf * BUF_HALFS + ks * 16 * PITCH + tro;
+        bf16x8_t ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[i] = tr_frag(img + wm * 128 + i * 32);
+            al[i] = tr_frag(img + PLANE_HALFS + wm * 128 + i * 32);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bh[j] = tr_frag(img + 2 * PLANE_HALFS + wn * 64 + j * 32);
+            bl[j] = tr_frag(img + 3 * PLANE_HALFS + wn * 64 + j * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+    };
+    // a raw barrier: __syncthreads() would also wait (vmcnt) for the loads of the step after next that are in flight
+#define T256_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+    load(0);
+    convert(0);
+    load(1);
+    T256_BARRIER();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (w < 4) {
+            if (kt + 1 < nk) convert(cur ^ 1);
+            load(kt + 2);
+            multiply(cur, 0);
+            multiply(cur, 1);
+        } else {
+            multiply(cur, 0);
+            if (kt + 1 < nk) convert(cur ^ 1);
+            load(kt + 2);
+            multiply(cur, 1);
+        }
+        T256_BARRIER();
+    }
+#undef T256_BARRIER
+
+    // raw alpha * acc into this item's slab (branch-free buffer stores)
+    float* slab = g.partial + (size_t)z * g.M * g.N;
+    __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)(unsigned)((size_t)g.M * g.N * 4), 0x00020000);
+    const int cl = lane & 31, rq = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned o0 = (unsigned)(((size_t)(m0 + wm * 128 + i * 32 + 4 * rq) * g.N + n0 + wn * 64 + j * 32 + cl) * 4);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(g.alpha * acc[i][j][r]), prs, o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.N * 4), 0, 0);
+        }
+    if (!g.queue) return;
+    __syncthreads();           // every read of this item's last buffer is done before the mailbox / the next item's images are written
+  }
+}
+}  // namespace t256
+
 // ---- internal entry points used by gemm_dma.hip's C ABI functions ----
 size_t pgasr_internal_x3c_slab_bytes() { return (size_t)c256::SLAB_FLOATS * 4; }
 
@@ -341,6 +511,37 @@ int pgasr_internal_x3c_launch(const PgasrX3cArgs& a, hipStream_t st) {
     for (int pass = 0; pass < 2; ++pass) {     // one persistent workgroup per CU; pass 1 ignores the busy counters
         if (pass == 1) g.xcc_busy = nullptr;
         PGASR_LAUNCH_KERNEL(c256::gemm_x3c_kernel<true>, dim3(256), dim3(c256::THREADS), lds, st, g);
+        PGASR_CHECK_LAUNCH();
+    }
+    return PGASR_OK;
+}
+
+bool pgasr_internal_tn256_ok(const PgasrTn256Args& a) {
+    // PGASR_TN_TILE=128 (read at every call) keeps gemm.hip's 128 x 128 kernel (A/B measurements)
+    const char* e = getenv("PGASR_TN_TILE");
+    if (e && e[0] == '1' && e[1] == '2' && e[2] == '8') return false;
+    if (!a.A || !a.B || !a.partial || a.M <= 0 || a.N <= 0 || a.K < 32 || a.batch <= 0 || a.splitk <= 0) return false;
+    if ((a.M % t256::TM) || (a.N % t256::TN) || (a.K % 32) || (a.kper % 32) || (a.lda & 3) || (a.ldb & 3)) return false;
+    if ((a.sA & 3) || (a.sB & 3) || (((size_t)a.A) & 15) || (((size_t)a.B) & 15)) return false;
+    if ((long long)(a.splitk - 1) * a.kper >= a.K) return false;        // no empty slab
+    if ((size_t)a.M * a.N * 4 >= ((size_t)1 << 32)) return false;
+    return true;
+}
+
+int pgasr_internal_tn256_launch(PgasrTn256Args a, int masked_then_unmasked, hipStream_t st) {
+    const size_t lds = (size_t)t256::LDS_BYTES;
+    if (hipFuncSetAttribute((const void*)t256::gemm_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PGASR_ERR_LAUNCH;
+    const unsigned nitems = (unsigned)((a.N / t256::TN) * (a.M / t256::TM)) * (unsigned)(a.batch * a.splitk);
+    if (!a.queue) {
+        PGASR_LAUNCH_KERNEL(t256::gemm_t256_kernel, dim3(nitems), dim3(t256::THREADS), lds, st, a);
+        PGASR_CHECK_LAUNCH();
+        return PGASR_OK;
+    }
+    const unsigned* busy = a.xcc_busy;
+    for (int pass = 0; pass < (masked_then_unmasked ? 2 : 1); ++pass) {
+        a.xcc_busy = (pass == 0) ? busy : nullptr;
+        PGASR_LAUNCH_KERNEL(t256::gemm_t256_kernel, dim3(256), dim3(t256::THREADS), lds, st, a);
         PGASR_CHECK_LAUNCH();
     }
     return PGASR_OK;

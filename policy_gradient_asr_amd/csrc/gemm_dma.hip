@@ -234,7 +234,7 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_x3w_kernel(DmaGemmArgs g) {
         __syncthreads();
         const unsigned before = *mailbox;
         __syncthreads();
-        if (before != 3u) continue;
+        if (before != 3u) { if (g.single) return; continue; }
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
@@ -298,6 +298,7 @@ __global__ __launch_bounds__(DMA_THREADS) void gemm_x3w_kernel(DmaGemmArgs g) {
     __syncthreads();
     if (tid == 0)
         __hip_atomic_fetch_add(g.tiles_done + (tbx < (g.nt_count >> 1) ? 0 : g.mt_count) + tby, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (g.single) return;
   }
 }
 
@@ -589,195 +590,6 @@ __global__ __launch_bounds__(THREADS) void gemm_x3w256_kernel(DmaGemmArgs g) {
 }
 }  // namespace w256
 
-// ------------------------------------------------------------------------------------------------------------------
-// Weight gradients dW = dY^T X (model.py:39-44 backward: dW_ih = dgates^T x, dW_hh = dgates^T h_prev) on the same
-// 256 x 256 tile: BOTH operands are fp32 activations stored k-major (rows = (t, b), the M / N index contiguous), K is
-// the long dimension (T*B = 32000) and the output is small, so the product is split over K into slabs that the
-// existing gemm_reduce_kernel sums in index order (deterministic).
-//   * stage = one 16-deep k-step: A[16][256] + B[16][256] fp32 = 32 KB, four stages; a DMA piece is one k-row of one
-//     operand (1 KB contiguous in HBM and in LDS: no swizzle needed);
-//   * an MFMA operand wants 8 k-values of ONE m per lane: ds_read2st64_b32 picks two of them (rows are 1 KB = 4 x 64
-//     dwords apart) per instruction, consecutive lanes read consecutive dwords -- conflict-free; which 8 k a lane holds
-//     (k = 8 (lane / 32) + e) is the same for both operands, which is all the MFMA needs;
-//   * both fragments are split into bf16 hi / lo in registers (this kernel is VALU-heavier than the NT one: 64 values
-//     per lane and k-step instead of 32).
-// ------------------------------------------------------------------------------------------------------------------
-namespace tn256 {
-constexpr int TM = 256, TN = 256, TK = 16, NST = 4, THREADS = 256;
-constexpr int OP_BYTES = TK * TM * 4;                // 16 KB per operand
-constexpr int STAGE_BYTES = 2 * OP_BYTES;            // 32 KB
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-
-struct RawOp { u32x2_t v[4][4]; };          // tile x k-pair: values k = 8 kg + 2 p, + 1
-
-__device__ __forceinline__ void read_op(RawOp& r, unsigned p0, unsigned p1, unsigned p2, unsigned p3) {
-    asm volatile("ds_read2st64_b32 %0, %16 offset0:0 offset1:4\n\t"
-                 "ds_read2st64_b32 %1, %16 offset0:8 offset1:12\n\t"
-                 "ds_read2st64_b32 %2, %16 offset0:16 offset1:20\n\t"
-                 "ds_read2st64_b32 %3, %16 offset0:24 offset1:28\n\t"
-                 "ds_read2st64_b32 %4, %17 offset0:0 offset1:4\n\t"
-                 "ds_read2st64_b32 %5, %17 offset0:8 offset1:12\n\t"
-                 "ds_read2st64_b32 %6, %17 offset0:16 offset1:20\n\t"
-                 "ds_read2st64_b32 %7, %17 offset0:24 offset1:28\n\t"
-                 "ds_read2st64_b32 %8, %18 offset0:0 offset1:4\n\t"
-                 "ds_read2st64_b32 %9, %18 offset0:8 offset1:12\n\t"
-                 "ds_read2st64_b32 %10, %18 offset0:16 offset1:20\n\t"
-                 "ds_read2st64_b32 %11, %18 offset0:24 offset1:28\n\t"
-                 "ds_read2st64_b32 %12, %19 offset0:0 offset1:4\n\t"
-                 "ds_read2st64_b32 %13, %19 offset0:8 offset1:12\n\t"
-                 "ds_read2st64_b32 %14, %19 offset0:16 offset1:20\n\t"
-                 "ds_read2st64_b32 %15, %19 offset0:24 offset1:28"
-                 : "=&v"(r.v[0][0]), "=&v"(r.v[0][1]), "=&v"(r.v[0][2]), "=&v"(r.v[0][3]),
-                   "=&v"(r.v[1][0]), "=&v"(r.v[1][1]), "=&v"(r.v[1][2]), "=&v"(r.v[1][3]),
-                   "=&v"(r.v[2][0]), "=&v"(r.v[2][1]), "=&v"(r.v[2][2]), "=&v"(r.v[2][3]),
-                   "=&v"(r.v[3][0]), "=&v"(r.v[3][1]), "=&v"(r.v[3][2]), "=&v"(r.v[3][3])
-                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
-                 : "memory");
-}
-__device__ __forceinline__ void wait_ops(RawOp& a, RawOp& b) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a.v[0][0]), "+v"(a.v[0][1]), "+v"(a.v[0][2]), "+v"(a.v[0][3]),
-                   "+v"(a.v[1][0]), "+v"(a.v[1][1]), "+v"(a.v[1][2]), "+v"(a.v[1][3]),
-                   "+v"(a.v[2][0]), "+v"(a.v[2][1]), "+v"(a.v[2][2]), "+v"(a.v[2][3]),
-                   "+v"(a.v[3][0]), "+v"(a.v[3][1]), "+v"(a.v[3][2]), "+v"(a.v[3][3])
-                 :: "memory");
-    asm volatile(""
-                 : "+v"(b.v[0][0]), "+v"(b.v[0][1]), "+v"(b.v[0][2]), "+v"(b.v[0][3]),
-                   "+v"(b.v[1][0]), "+v"(b.v[1][1]), "+v"(b.v[1][2]), "+v"(b.v[1][3]),
-                   "+v"(b.v[2][0]), "+v"(b.v[2][1]), "+v"(b.v[2][2]), "+v"(b.v[2][3]),
-                   "+v"(b.v[3][0]), "+v"(b.v[3][1]), "+v"(b.v[3][2]), "+v"(b.v[3][3])
-                 :: "memory");
-}
-__device__ __forceinline__ void split_tile(const u32x2_t (&v)[4], bf16x8_t& hi, bf16x8_t& lo) {
-    u32x4_t h, l;
-    unsigned a, b;
-    split2(__uint_as_float(v[0].x), __uint_as_float(v[0].y), a, b); h.x = a; l.x = b;
-    split2(__uint_as_float(v[1].x), __uint_as_float(v[1].y), a, b); h.y = a; l.y = b;
-    split2(__uint_as_float(v[2].x), __uint_as_float(v[2].y), a, b); h.z = a; l.z = b;
-    split2(__uint_as_float(v[3].x), __uint_as_float(v[3].y), a, b); h.w = a; l.w = b;
-    hi = __builtin_bit_cast(bf16x8_t, h); lo = __builtin_bit_cast(bf16x8_t, l);
-}
-
-__global__ __launch_bounds__(THREADS) void gemm_tn256_kernel(PgasrTn256Args g) {
-    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;
-    if (g.queue && g.xcc_busy) {
-        const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;
-        if (__hip_atomic_load(g.xcc_busy + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-    }
-    const int tx = g.N / TN, ty = g.M / TM;
-    const unsigned nitems = (unsigned)(tx * ty) * (unsigned)(g.batch * g.splitk);
-  for (;;) {
-    unsigned item;
-    if (g.queue) {
-        unsigned* mailbox = reinterpret_cast<unsigned*>(smem + NST * STAGE_BYTES);
-        if (tid == 0) *mailbox = __hip_atomic_fetch_add(g.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        item = *mailbox;
-        __syncthreads();
-    } else {
-        item = blockIdx.x;
-    }
-    if (item >= nitems) return;
-    // items of one K-slab are adjacent (they run at the same time and share the slab's rows in L2 / MALL)
-    const int z = (int)(item / (unsigned)(tx * ty)), t2 = (int)(item % (unsigned)(tx * ty));
-    const int tbx = t2 % tx, tby = t2 / tx;
-    const int bidx = z / g.splitk, sidx = z % g.splitk;
-    const int k_beg = sidx * g.kper, k_end = (k_beg + g.kper < g.K) ? k_beg + g.kper : g.K;
-    const int nk = k_end > k_beg ? (k_end - k_beg) / TK : 0;        // even (K, kper multiples of 32)
-    const int m0 = tby * TM, n0 = tbx * TN;
-    const float* Ab = g.A + (size_t)bidx * g.sA + m0 + 4 * lane;
-    const float* Bb = g.B + (size_t)bidx * g.sB + n0 + 4 * lane;
-
-    auto issue = [&](int kt, int stage) {      // ALWAYS 8 wave-instructions: wave w moves k-rows 4j + w of both operands
-        int k0 = k_beg + (kt < nk ? kt : (nk > 0 ? nk - 1 : 0)) * TK;
-        if (k0 + TK > g.K) k0 = g.K - TK;
-        unsigned char* sa = smem + stage * STAGE_BYTES;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma16(Ab + (size_t)(k0 + 4 * j + w) * g.lda, sa + (4 * j + w) * 1024);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma16(Bb + (size_t)(k0 + 4 * j + w) * g.ldb, sa + OP_BYTES + (4 * j + w) * 1024);
-    };
-
-    const int fr = lane & 31, fh = lane >> 5;
-    unsigned offA[4], offB[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        offA[i] = (unsigned)(fh * 8 * 1024 + (wm * 128 + i * 32 + fr) * 4);
-        offB[i] = (unsigned)(OP_BYTES + fh * 8 * 1024 + (wn * 128 + i * 32 + fr) * 4);
-    }
-
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    RawOp ra, rb;
-#pragma unroll
-    for (int s = 0; s < NST; ++s) issue(s, s);
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    read_op(ra, lds0 + offA[0], lds0 + offA[1], lds0 + offA[2], lds0 + offA[3]);
-    read_op(rb, lds0 + offB[0], lds0 + offB[1], lds0 + offB[2], lds0 + offB[3]);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        wait_ops(ra, rb);
-        bf16x8_t ah[4], al[4], bh[4], bl[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { split_tile(ra.v[i], ah[i], al[i]); split_tile(rb.v[i], bh[i], bl[i]); }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const unsigned sb = lds0 + (unsigned)((kt + 1) & 3) * STAGE_BYTES;
-        read_op(ra, sb + offA[0], sb + offA[1], sb + offA[2], sb + offA[3]);
-        read_op(rb, sb + offB[0], sb + offB[1], sb + offB[2], sb + offB[3]);
-        issue(kt + NST, kt & 3);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[3][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[3], bh[j], acc[3][j], 0, 0, 0);
-            acc[3][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[3], bl[j], acc[3][j], 0, 0, 0);
-            acc[3][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[3], bh[j], acc[3][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    wait_ops(ra, rb);
-
-    // raw alpha * acc into this item's slab: 32x32 accumulator layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* slab = g.partial + (size_t)z * g.M * g.N;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 128 + j * 32 + fr;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                slab[(size_t)m * g.N + n] = g.alpha * acc[i][j][r];
-            }
-        }
-    if (!g.queue) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every DMA of this item has retired before the stages are reused
-    __syncthreads();
-  }
-}
-}  // namespace tn256
-
 // fp32 (rows x cols, leading dim ld) -> dense bf16 hi / lo planes; transpose: planes are (cols x rows)
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int rows, int cols, int ld,
                                                            int transpose, unsigned short* __restrict__ hi,
@@ -835,6 +647,25 @@ extern "C" int pgasr_gemm_x3w_feed_col_tiles(int N) {
     return N / (2 * TN);
 }
 
+// Work items in the first `groups` tile groups of a feed (a group = the column tiles of row tile i of one direction half and
+// of row tile last - i of the other): what a HEAD launch (phase 1) computes.  0: no head for this shape / tile structure
+// (the 256-wide feeds have none), or more items than one wave of workgroups.
+extern "C" int pgasr_gemm_x3w_feed_head_items(int N, int K, int groups) {
+    if (groups <= 0 || N <= 0 || K <= 0 || (N % (2 * TN)) || (K % TK) || x3w_tile_mode(true) != 0) return 0;
+    const int nt = N / TN;
+    long long tiles = (long long)groups * nt;
+    int items;
+    if (x3w_quarters(K) == 4) {
+        long long split = 16LL * nt;
+        if (split > FEED_SPLIT_MAX) split = FEED_SPLIT_MAX;
+        if (tiles > split) return 0;              // a head stays inside the quarter-split tiles (the host sizes the workspace for them)
+        items = (int)(4 * tiles);
+    } else {
+        items = (int)tiles;
+    }
+    return items <= 256 ? items : 0;
+}
+
 extern "C" size_t pgasr_gemm_x3w_feed_workspace_bytes(void) { return 1024 + (size_t)FEED_SPLIT_MAX * 4 * 64 * 512 * 4; }
 
 extern "C" int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
@@ -880,10 +711,11 @@ extern "C" int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, 
 //                are computed as four parallel K-quarters (same bits, a quarter of the latency)
 extern "C" int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
                                        const unsigned short* Wlo, float* C, int ldc, const float* bias,
-                                       const unsigned* xcc_busy, unsigned* tiles_done, int order, void* workspace,
-                                       size_t workspace_bytes, void* stream) {
+                                       const unsigned* xcc_busy, unsigned* tiles_done, int order, int phase, int head_groups,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
     if (!A || !Whi || !Wlo || !C || !tiles_done || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N) return PGASR_ERR_INVALID_ARG;
-    if (order < 0 || order > 1) return PGASR_ERR_INVALID_ARG;
+    if (order < 0 || order > 1 || phase < 0 || phase > 2 || head_groups < 0) return PGASR_ERR_INVALID_ARG;
+    if (phase != 0 && pgasr_gemm_x3w_feed_head_items(N, K, head_groups) <= 0) return PGASR_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < 1024) return PGASR_ERR_WORKSPACE;
     if ((K % TK) || (N % (2 * TN)) || (lda & 3) || (((size_t)A) & 15) || (((size_t)Whi) & 15) || (((size_t)Wlo) & 15))
         return PGASR_ERR_UNSUPPORTED;
@@ -934,7 +766,7 @@ extern "C" int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int 
     const size_t lds = (size_t)NST * STAGE_BYTES + 16;
     if (hipFuncSetAttribute((const void*)gemm_x3w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
-    if (hipMemsetAsync(workspace, 0, 1024, st) != hipSuccess) return PGASR_ERR_LAUNCH;   // tile counter + arrival counters
+    if (phase != 2 && hipMemsetAsync(workspace, 0, 1024, st) != hipSuccess) return PGASR_ERR_LAUNCH;   // tile counter + arrival counters
     // the first tile groups (16 time-ordered groups, at most FEED_SPLIT_MAX tiles and what the workspace holds) are split
     // into K-quarters: the sweep is waiting for exactly these
     const int quarters = x3w_quarters(K);
@@ -947,43 +779,19 @@ extern "C" int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int 
         if (split > mt * nt) split = mt * nt;
     }
     DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, nullptr, 0.f, (unsigned*)workspace, xcc_busy, tiles_done, mt, nt, order,
-                  quarters, split, (float*)((char*)workspace + 1024), (unsigned*)workspace + 64};
+                  quarters, split, (float*)((char*)workspace + 1024), (unsigned*)workspace + 64, 0};
+    if (phase == 1) {
+        // HEAD: the first `head_groups` tile groups, one work item per workgroup, no XCD mask -- launched on the sweep's own
+        // stream IN FRONT of the sweep, whose first rows are then in memory when it starts; phase 2 continues the queue
+        g.single = 1; g.xcc_busy = nullptr;
+        PGASR_LAUNCH_KERNEL(gemm_x3w_kernel<true>, dim3((unsigned)pgasr_gemm_x3w_feed_head_items(N, K, head_groups)), dim3(DMA_THREADS), lds, st, g);
+        PGASR_CHECK_LAUNCH();
+        return PGASR_OK;
+    }
     // one persistent workgroup per CU (144 KB of LDS each); pass 1 ignores the busy counters
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) g.xcc_busy = nullptr;
         PGASR_LAUNCH_KERNEL(gemm_x3w_kernel<true>, dim3(256), dim3(DMA_THREADS), lds, st, g);
-        PGASR_CHECK_LAUNCH();
-    }
-    return PGASR_OK;
-}
-
-bool pgasr_internal_tn256_ok(const PgasrTn256Args& a) {
-    // opt-in (PGASR_TN_TILE=256, read at every call) until it wins where it is used: measured round 3 on the dW_ih shape
-    // (2048 x 512 x 32000), whole chip: split-K 16 (256 items) 232 us against 275 us for the 128 x 128 kernel at its best
-    // split (8) -- but with the 128 items that fit beside a sweep (split-K 8) 415 us against 275.
-    const char* e = getenv("PGASR_TN_TILE");
-    if (!(e && e[0] == '2' && e[1] == '5' && e[2] == '6')) return false;
-    if (!a.A || !a.B || !a.partial || a.M <= 0 || a.N <= 0 || a.K < 32 || a.batch <= 0 || a.splitk <= 0) return false;
-    if ((a.M % tn256::TM) || (a.N % tn256::TN) || (a.K % 32) || (a.kper % 32) || (a.lda & 3) || (a.ldb & 3)) return false;
-    if ((a.sA & 3) || (a.sB & 3) || (((size_t)a.A) & 15) || (((size_t)a.B) & 15)) return false;
-    if ((long long)(a.splitk - 1) * a.kper >= a.K) return false;        // no empty slab
-    return true;
-}
-
-int pgasr_internal_tn256_launch(PgasrTn256Args a, int masked_then_unmasked, hipStream_t st) {
-    const size_t lds = (size_t)tn256::NST * tn256::STAGE_BYTES + 16;
-    if (hipFuncSetAttribute((const void*)tn256::gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return PGASR_ERR_LAUNCH;
-    const unsigned nitems = (unsigned)((a.N / tn256::TN) * (a.M / tn256::TM)) * (unsigned)(a.batch * a.splitk);
-    if (!a.queue) {
-        PGASR_LAUNCH_KERNEL(tn256::gemm_tn256_kernel, dim3(nitems), dim3(tn256::THREADS), lds, st, a);
-        PGASR_CHECK_LAUNCH();
-        return PGASR_OK;
-    }
-    const unsigned* busy = a.xcc_busy;
-    for (int pass = 0; pass < (masked_then_unmasked ? 2 : 1); ++pass) {
-        a.xcc_busy = (pass == 0) ? busy : nullptr;
-        PGASR_LAUNCH_KERNEL(tn256::gemm_tn256_kernel, dim3(256), dim3(tn256::THREADS), lds, st, a);
         PGASR_CHECK_LAUNCH();
     }
     return PGASR_OK;

@@ -25,6 +25,7 @@ struct DmaGemmArgs {
     int split_tiles;            // FEED: tiles (in queue order) whose quarters are separate work items
     float* slabs;               // FEED: [split_tiles][4][64][512] partial accumulators
     unsigned* arrive;           // FEED: [split_tiles] quarters finished (zeroed by the host)
+    int single;                 // FEED: every workgroup takes ONE work item and leaves (the head launch in front of a sweep)
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_base) {

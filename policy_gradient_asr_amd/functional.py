@@ -14,7 +14,19 @@ FEED_BWD = os.environ.get("PGASR_FEED_BWD", "1") != "0"       # .. and the upper
 LEAKY_SLOPE = 0.01   # F.leaky_relu default, model.py:50
 
 
-def _pick_splitk(M, N, K, target_wgs=512):     # 2 workgroups per CU; measured on dW_ih (2048x512x32000): 4 -> 508 us, 8 -> 326 us
+def _pick_splitk(M, N, K, target_wgs=512, batch=1, beside_sweep=False):
+    """Split-K factor of a weight-gradient product.  Shapes the 256 x 256 TN kernel takes (gemm_c256.hip: M, N % 256 == 0,
+    K % 32 == 0, one workgroup per CU) get one work item per available CU: 128 beside a sweep (it leaves four XCDs
+    free), 256 in the tail -- measured round 3 on dW_ih (2048 x 512 x 32000): 128 items 345 us on half the chip (the
+    128 x 128 kernel: ~510 us there), 256 items 224 us on the whole chip (276 us).  Other shapes: 128 x 128 tiles, 2 workgroups
+    per CU (measured on dW_ih: 4 -> 508 us, 8 -> 326 us).  A function of the layer's shapes only, never of the overlap
+    mode, so that every mode gives the same bits."""
+    if M % 256 == 0 and N % 256 == 0 and K % 32 == 0 and K >= 64:
+        tiles = (M // 256) * (N // 256) * batch
+        sk = max(1, min((128 if beside_sweep else 256) // tiles, K // 256))
+        while sk > 1 and (sk - 1) * (-(-K // sk // 32) * 32) >= K:     # no empty slab once slabs are rounded up to 32
+            sk -= 1
+        return sk
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     sk = max(1, min(64, target_wgs // max(tiles, 1)))
     while sk > 1 and K // sk < 256:
@@ -295,6 +307,12 @@ class BLSTMLayerFn(torch.autograd.Function):
             prepacked.fed_fwd = None          # single use
             if done is None:
                 done = torch.zeros(need_words, dtype=torch.int32, device=x.device)
+            # HEAD: the first tile groups of the projection are computed on THIS stream in front of the sweep (one work item
+            # per workgroup, whole chip, ~30 us), so that the rows of the sweep's first steps are in memory when it starts;
+            # without it a fed sweep sits ~50-70 us on its first rows (stream gate + launch + first tiles).  The rest of
+            # the queue follows on the feed stream as before.
+            head = hipops.x3w_feed_head_items(G, I) > 0
+            ws_feed = hipops.gemm_x3w_feed(x, prepacked.planes, gates, T * B, G, I, bias_perm, 0, done, phase=1) if head else None
             zeroed = torch.cuda.Event()
             zeroed.record()
             hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, fed=done, fed_need=hipops.x3w_feed_col_tiles(G), **dkw)
@@ -302,7 +320,9 @@ class BLSTMLayerFn(torch.autograd.Function):
             busy = hipops.lstm_busy_ptr(T, B, False, x.device)
             with torch.cuda.stream(side):
                 hipops.stream_gate(busy)
-                hipops.gemm_x3w_feed(x, prepacked.planes, gates, T * B, G, I, bias_perm, busy, done)
+                hipops.gemm_x3w_feed(x, prepacked.planes, gates, T * B, G, I, bias_perm, busy, done, phase=2 if head else 0, ws=ws_feed)
+            if ws_feed is not None:
+                streams.hold(ws_feed, side)
             for t_ in (x, gates, done, bias_perm) + tuple(prepacked.planes):
                 streams.hold(t_, side)
             grad_overlap._feed_unjoined[main.cuda_stream] = True
@@ -347,7 +367,11 @@ class BLSTMLayerFn(torch.autograd.Function):
                 before.record()
         if rec is not None:
             # dout does not exist yet: the layer above left its input-gradient GEMM (and the dropout between the layers)
-            # to us.  The sweep goes first; the GEMM follows on the side stream and feeds it row tile by row tile.
+            # to us.  Its first tile groups are computed here, in front of the sweep; then the sweep goes, and the rest of
+            # the GEMM follows on the side stream and feeds it row tile by row tile.
+            if grad_overlap.enabled and rec["head"]():
+                before = torch.cuda.Event()       # the side stream's part must come behind the head (one queue)
+                before.record()
             _, dbias_part = hipops.lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=True,
                                                   fed=rec["done"], fed_need=rec["need"], drop=rec["drop"])
         else:
@@ -382,12 +406,23 @@ class BLSTMLayerFn(torch.autograd.Function):
                 done = torch.zeros(need_words, dtype=torch.int32, device=dev)
             planes_t = ctx.planes_t
 
+            feed_ws = []
+
+            def head(dg=dg, dx=dx, done=done, planes_t=planes_t):
+                """On the consuming sweep's stream, in front of its launch: the first tile groups (see the forward path)."""
+                if hipops.x3w_feed_head_items(I, G) > 0:
+                    feed_ws.append(hipops.gemm_x3w_feed(dg, planes_t, dx, T * B, I, G, None, 0, done, order=1, phase=1))
+                    return True
+                return False
+
             def launch(busy_ptr, dg=dg, dx=dx, done=done, planes_t=planes_t):
-                hipops.gemm_x3w_feed(dg, planes_t, dx, T * B, I, G, None, busy_ptr, done, order=1)
+                hipops.gemm_x3w_feed(dg, planes_t, dx, T * B, I, G, None, busy_ptr, done, order=1,
+                                     phase=2 if feed_ws else 0, ws=feed_ws[0] if feed_ws else None)
                 side_ = torch.cuda.current_stream()
-                for t_ in (dg, dx, done) + tuple(planes_t):
+                for t_ in (dg, dx, done) + tuple(planes_t) + tuple(feed_ws):
                     streams.hold(t_, side_)
-            grad_overlap._deferred[dx.data_ptr()] = {"dx": dx, "done": done, "need": hipops.x3w_feed_col_tiles(I), "drop": None, "launch": launch}
+            grad_overlap._deferred[dx.data_ptr()] = {"dx": dx, "done": done, "need": hipops.x3w_feed_col_tiles(I), "drop": None,
+                                                     "launch": launch, "head": head}
         elif ctx.needs_input_grad[0]:
             dx = torch.empty(T, B, I, dtype=torch.float32, device=dev)
             if (ctx.sweep_follows and not ctx.has_dact and ctx.planes_t is not None and hipops.gemm_x3w_ok(T * B, I, G)
@@ -415,7 +450,7 @@ class BLSTMLayerFn(torch.autograd.Function):
                     K = (T - 1) * B
                     hipops.gemm(dg, out, dwhh_, M=4 * HID, N=HID, K=K, transA=True, lda=G, ldb=2 * HID, ldc=HID,
                                 a_off=B * G, b_off=0, strideA=4 * HID - B * G, strideB=B * 2 * HID + HID,
-                                strideC=4 * HID * HID, batch=2, splitk=_pick_splitk(4 * HID, HID, K, 256))   # x2 batches; measured 8 -> 272 us, 16 -> 173 us
+                                strideC=4 * HID * HID, batch=2, splitk=_pick_splitk(4 * HID, HID, K, 256, batch=2, beside_sweep=ctx.sweep_follows))   # x2 batches
                 return dwhh_
             if hh_stream is not None:
                 hh_stream.wait_stream(cur)
@@ -426,7 +461,7 @@ class BLSTMLayerFn(torch.autograd.Function):
                 streams.hold(dwhh, cur)
             dwih = torch.empty(G, I, dtype=torch.float32, device=dev)
             hipops.gemm(dg, x, dwih, M=G, N=I, K=T * B, transA=True, lda=G,
-                        splitk=_pick_splitk(G, I, T * B, 512 if ctx.sweep_follows else 256))    # first layer: three GEMMs share the chip in the tail -> fewer, longer slabs (0.86 -> 0.83 ms); by layer, not by mode, so that overlap on/off give the same bits
+                        splitk=_pick_splitk(G, I, T * B, 512 if ctx.sweep_follows else 256, beside_sweep=ctx.sweep_follows))    # by layer, not by mode, so that overlap on/off give the same bits
             dbias = torch.empty(G, dtype=torch.float32, device=dev)
             hipops.colsum(dbias_part, dbias_part.shape[0], G, G, dbias)      # the sweep summed dgates over t per group
             if hh_stream is not None:

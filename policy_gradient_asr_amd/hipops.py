@@ -1,7 +1,11 @@
 """Tensor-level wrappers over the C ABI (one function per entry point of
 include/pgasr_hip.h).  torch is used for device memory and the current stream only.
 Every wrapper requires CUDA(HIP) tensors and raises otherwise -- no CPU fallback."""
+import os
+
 import torch
+
+_os_environ_get = os.environ.get
 
 from . import _lib
 
@@ -506,8 +510,23 @@ def x3w_feed_col_tiles(N):
     return int(_lib.load().pgasr_gemm_x3w_feed_col_tiles(int(N)))
 
 
-def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done, order=0):
-    """``gemm_x3w`` in feed-ahead mode on the CURRENT stream (see include/pgasr_hip.h, pgasr_gemm_x3w_feed_f32)."""
+# Tile groups of a feeding GEMM computed IN FRONT of the fed sweep, on its own stream (pgasr_gemm_x3w_feed_f32 phase 1).
+# Off by default -- measured round 3 on one box, 40 + 100 steps each: the fed sweeps get shorter (forward 1.15 / 1.11 / 1.09 ->
+# 1.10 / 1.08 / 1.06 ms, backward 1.27 -> 1.23-1.25: they no longer sit ~40 us on their first rows) but the head launch itself
+# takes the ~30 us it saves, on the same critical stream: 8.49 ms per step without, 8.53 / 8.50 / 8.60 with 2 / 4 / 1 groups.
+FEED_HEAD_GROUPS = int(_os_environ_get("PGASR_FEED_HEAD", "0"))
+
+
+def x3w_feed_head_items(N, K, groups=None):
+    """Work items of a feed's HEAD launch (0: this shape / tile structure has none)."""
+    groups = FEED_HEAD_GROUPS if groups is None else groups
+    return int(_lib.load().pgasr_gemm_x3w_feed_head_items(int(N), int(K), int(groups))) if groups > 0 else 0
+
+
+def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done, order=0, phase=0, ws=None):
+    """``gemm_x3w`` in feed-ahead mode on the CURRENT stream (see include/pgasr_hip.h, pgasr_gemm_x3w_feed_f32).
+    phase 1 (head, on the sweep's stream in front of the sweep) returns the workspace that the phase-2 call (rest, on
+    the feeding stream) must be given as ``ws``: both work on one queue."""
     lib = _lib.load()
     hi, lo = planes
     for t, nm in ((A, "A"), (C, "C"), (bias, "bias")):
@@ -517,11 +536,13 @@ def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done, order=0):
         raise _lib.PgasrError("gemm_x3w_feed planes must be contiguous int16 (N, K)")
     if tiles_done.dtype != torch.int32 or tiles_done.numel() < 2 * ((M + 255) // 256):
         raise _lib.PgasrError("gemm_x3w_feed: tiles_done must hold 2 * ceil(M/256) int32 words")
-    ws = _workspace(lib.pgasr_gemm_x3w_feed_workspace_bytes(), C.device, "x3w_feed")
+    if ws is None:
+        ws = _workspace(lib.pgasr_gemm_x3w_feed_workspace_bytes(), C.device, "x3w_feed")
     st = lib.pgasr_gemm_x3w_feed_f32(M, N, K, A.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), C.data_ptr(), N, _p(bias),
-                                     busy_ptr, tiles_done.data_ptr(), int(order), _p(ws), ws.numel(), _stream())
+                                     busy_ptr, tiles_done.data_ptr(), int(order), int(phase), FEED_HEAD_GROUPS if phase else 0,
+                                     _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_gemm_x3w_feed_f32")
-    return C
+    return ws if phase == 1 else C
 
 
 def lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=False, fed=None, fed_need=0, drop=None):
