@@ -91,11 +91,13 @@ int pgasr_pg_loss_value(const float* log_probs, const int32_t* path, const int32
  *   scores (T,B,V) fp32 logits or log-probs (softmax is shift invariant).
  *   greedy_path[t,b] = argmax_v scores[t,b,v], first max wins  (oracle: numpy argmax)
  *   sample_path[t,b] ~ softmax(scores[t,b,:]) by inverse CDF with
- *        u = (philox4x32_10(ctr=(t*B+b, offset,0,0), key=(seed_lo,seed_hi)).x >> 8) * 2^-24
- *   Either output may be NULL.  V <= 64.
+ *        u = (philox4x32_10(ctr=(t*ctr_stride+ctr_base+b, offset,0,0), key=(seed_lo,seed_hi)).x >> 8) * 2^-24
+ *   ctr_stride = 0 means B (counter t*B+b, the single-process layout); a data-parallel rank passes the GLOBAL batch as
+ *   ctr_stride and its first utterance's global index as ctr_base (ctr_base + B <= ctr_stride), so that N ranks with one
+ *   seed draw what one process holding the whole batch draws.  Either output may be NULL.  V <= 64.
  * ---------------------------------------------------------------------------------------- */
 int pgasr_frame_argmax_sample(const float* scores, int T, int B, int V,
-                              uint64_t seed, uint32_t offset,
+                              uint64_t seed, uint32_t offset, int ctr_stride, int ctr_base,
                               int32_t* greedy_path, int32_t* sample_path, void* stream);
 
 /* ------------------------------------------------------------------------------------------

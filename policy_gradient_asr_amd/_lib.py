@@ -31,7 +31,7 @@ SIGNATURES = {
     "pgasr_pg_rewards": (C.c_int, [c_i32p, c_i32p, C.c_int, C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_ptr]),
     "pgasr_pg_loss_value": (C.c_int, [c_f32p, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                       c_f32p, c_ptr]),
-    "pgasr_frame_argmax_sample": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32,
+    "pgasr_frame_argmax_sample": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
                                             c_i32p, c_i32p, c_ptr]),
     "pgasr_batch_prep": (C.c_int, [c_f32p, C.c_int, C.c_int, c_ptr, c_ptr, C.c_int, c_i32p, c_i32p, c_i32p, c_ptr]),
     "pgasr_ctc_collapse": (C.c_int, [c_i32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, c_ptr]),

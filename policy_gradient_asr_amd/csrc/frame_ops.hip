@@ -10,7 +10,7 @@ namespace {
 // one wave per (t,b) row
 __global__ __launch_bounds__(256) void frame_argmax_sample_kernel(
     const float* __restrict__ scores, long long rows, int B, int V, uint32_t k0, uint32_t k1,
-    uint32_t offset, int32_t* __restrict__ greedy, int32_t* __restrict__ sample) {
+    uint32_t offset, int ctr_stride, int ctr_base, int32_t* __restrict__ greedy, int32_t* __restrict__ sample) {
     const int lane = threadIdx.x & 63;
     const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -35,7 +35,10 @@ __global__ __launch_bounds__(256) void frame_argmax_sample_kernel(
         }
         const float total = __shfl(c, 63, 64);
         uint32_t rnd[4];
-        philox4x32_10((uint32_t)r, offset, 0u, 0u, k0, k1, rnd);
+        // the draw of frame t of utterance b is addressed by t * ctr_stride + ctr_base + b: with stride = the GLOBAL batch and
+        // base = this rank's first utterance, N ranks draw exactly what one process holding the whole batch draws
+        const long long ctr = (r / B) * (long long)ctr_stride + ctr_base + (r % B);
+        philox4x32_10((uint32_t)ctr, offset, 0u, 0u, k0, k1, rnd);
         const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
         const float thr = u * total;
         // k = number of labels whose inclusive cdf <= u  (oracle: (cdf <= u).sum())
@@ -169,16 +172,18 @@ extern "C" int pgasr_log_softmax_rows(const float* logits, long long rows, int V
 }
 
 extern "C" int pgasr_frame_argmax_sample(const float* scores, int T, int B, int V,
-                                         uint64_t seed, uint32_t offset,
+                                         uint64_t seed, uint32_t offset, int ctr_stride, int ctr_base,
                                          int32_t* greedy_path, int32_t* sample_path, void* stream) {
     if (!scores || T <= 0 || B <= 0 || V <= 0) return PGASR_ERR_INVALID_ARG;
+    if (ctr_stride == 0) ctr_stride = B;              // the single-process layout: counter = t * B + b
+    if (ctr_stride < B || ctr_base < 0 || ctr_base + B > ctr_stride) return PGASR_ERR_INVALID_ARG;
     if (V > 64) return PGASR_ERR_UNSUPPORTED;
     if (!greedy_path && !sample_path) return PGASR_OK;
     const long long rows = (long long)T * B;
     const unsigned blocks = (unsigned)((rows + 3) / 4);
     PGASR_LAUNCH_KERNEL(frame_argmax_sample_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        scores, rows, B, V, (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), offset,
-                       greedy_path, sample_path);
+                       ctr_stride, ctr_base, greedy_path, sample_path);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }

@@ -25,6 +25,7 @@
 // M * ldc * 4 < 2^32 and M * lda * 4 < 2^32.
 #include "common.h"
 #include "x3w_common.h"
+#include <type_traits>
 
 namespace {
 namespace c256 {
@@ -33,8 +34,9 @@ constexpr int AP_BYTES = TM * TK * 2;            // one A plane of one buffer: 1
 constexpr int ABUF_BYTES = 2 * AP_BYTES;         // hi | lo
 constexpr int WP_BYTES = TN * TK * 2;            // one W plane of one stage: 16 KB
 constexpr int WSTAGE_BYTES = 2 * WP_BYTES;       // hi | lo
-constexpr int LDS_W = 2 * ABUF_BYTES;            // [A buffer 0][A buffer 1][W stage 0][W stage 1][mailbox]
-constexpr int LDS_BYTES = LDS_W + 2 * WSTAGE_BYTES;      // 128 KB
+constexpr int LDS_W = 2 * ABUF_BYTES;            // [A buffer 0][A buffer 1][W stages ...][mailbox (FEED)]
+constexpr int LDS_BYTES = LDS_W + 2 * WSTAGE_BYTES;      // 128 KB: the FEED kernel (two W stages, loads one step ahead)
+constexpr int LDS_BYTES_DEEP = LDS_W + 3 * WSTAGE_BYTES; // 160 KB: the plain kernel (three W stages, A loads two steps ahead)
 constexpr int SLAB_FLOATS = 128 * THREADS;       // one parked accumulator set: 256 KB
 
 struct Frag { u32x4_t ah[4], al[4], bh[2], bl[2]; };
@@ -73,8 +75,31 @@ __device__ __forceinline__ void write_planes(unsigned addr, unsigned h0, unsigne
                  "ds_write_b64 %0, %2 offset:16384" :: "v"(addr), "v"(h), "v"(l) : "memory");
 }
 
+// DEEP (= !FEED, the plain launches): A loads run TWO steps ahead (two register sets) and W has three LDS stages.  What a
+// CU pulls through its memory pipeline is in-flight bytes / latency, and one step of lead left 64 KB in flight per CU
+// (measured: ~18 GB/s per CU with every CU pulling, the same as the 128-wide kernels); the FEED kernel keeps one step of
+// lead (its 256 registers are full, and feeds default to the 256 x 128 kernel anyway).
+// (free functions: clang rejects inline-asm operands that name captured variables inside a generic lambda)
+__device__ __forceinline__ void load_a_regs(u32x4_t (&r)[4], const unsigned (&aoff)[4], unsigned kb, const float* A) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r[j]) : "v"(aoff[j] + kb), "s"(A) : "memory");
+}
+template <int HALF>
+__device__ __forceinline__ void load_a_pair(u32x4_t (&r)[4], const unsigned (&aoff)[4], unsigned kb, const float* A) {
+#pragma unroll
+    for (int j = 2 * HALF; j < 2 * HALF + 2; ++j)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r[j]) : "v"(aoff[j] + kb), "s"(A) : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void wait_a_regs(u32x4_t (&r)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(CNT) : "memory");
+}
+
 template <bool FEED>
 __global__ __launch_bounds__(THREADS) void gemm_x3c_kernel(DmaGemmArgs g) {
+    constexpr bool DEEP = !FEED;
+    constexpr int NW = DEEP ? 3 : 2, NA = DEEP ? 2 : 1, VMW = DEEP ? 12 : 4, VMX = DEEP ? 8 : 0;
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];   // the ONLY LDS object
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 2, wn = w & 3;
@@ -84,7 +109,6 @@ __global__ __launch_bounds__(THREADS) void gemm_x3c_kernel(DmaGemmArgs g) {
         if (__hip_atomic_load(g.xcc_busy + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const int diag = FEED ? 0 : g.quarters;      // plain launches carry a diagnostic code there (PGASR_X3W_DIAG; results invalid)
   for (;;) {
     int tbx, tby;
     int kt0 = 0, kt1 = nk, qpart = -1;      // step range of this work item; qpart >= 0: one quarter of a split tile
@@ -126,33 +150,44 @@ __global__ __launch_bounds__(THREADS) void gemm_x3c_kernel(DmaGemmArgs g) {
         const size_t o = (size_t)(n0 + row) * g.K + c * 8;
         ph[j] = g.Whi + o; pl[j] = g.Wlo + o;
     }
-    auto issue_w = [&](int kt, int stage) {      // ALWAYS 4 wave-instructions (k clamped), so the counted waits are exact
+    auto issue_w2 = [&](int kt, int stage, int plane) {     // two of a step's four W pieces: the hi (0) or the lo (1) plane
         const int k0 = (kt < nk ? kt : nk - 1) * TK;
-        unsigned char* ws = smem + LDS_W + stage * WSTAGE_BYTES;
+        unsigned char* ws = smem + LDS_W + stage * WSTAGE_BYTES + plane * WP_BYTES;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) dma16(ph[j] + k0, ws + (w + 8 * j) * 1024);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) dma16(pl[j] + k0, ws + WP_BYTES + (w + 8 * j) * 1024);
+        for (int j = 0; j < 2; ++j) dma16((plane ? pl[j] : ph[j]) + k0, ws + (w + 8 * j) * 1024);
     };
-    u32x4_t araw[4];
+    auto issue_w = [&](int kt, int stage) {      // ALWAYS 4 wave-instructions per step (k clamped), so the counted waits are exact
+        issue_w2(kt, stage, 0); issue_w2(kt, stage, 1);
+    };
+    u32x4_t araw[NA][4];
     // ALWAYS 4 loads, in inline asm: a load hipcc can see is waited for with s_waitcnt vmcnt(0) where its registers are
     // handed to the asm wait below -- which would also drain the W pieces issued just before (seen in the .s)
-    auto load_a = [&](int kt) {
+    auto load_a = [&](int kt, auto setc) {        // the register set is a compile-time index
         const unsigned kb = (unsigned)((kt < nk ? kt : nk - 1) * TK * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(araw[j]) : "v"(aoff[j] + kb), "s"(g.A) : "memory");
+        load_a_regs(araw[decltype(setc)::value], aoff, kb, g.A);
     };
-    auto convert_a = [&](int buf) {               // araw -> hi / lo planes of buffer `buf`
+    auto load_a2 = [&](int kt, auto setc, auto halfc) {     // two of a step's four A loads
+        const unsigned kb = (unsigned)((kt < nk ? kt : nk - 1) * TK * 4);
+        load_a_pair<decltype(halfc)::value>(araw[decltype(setc)::value], aoff, kb, g.A);
+    };
+    auto wait_a = [&](auto setc, auto cntc) {     // s_waitcnt vmcnt(CNT) that claims the set's registers
+        wait_a_regs<decltype(cntc)::value>(araw[decltype(setc)::value]);
+    };
+    auto convert_a = [&](int buf, auto setc) {    // register set -> hi / lo planes of buffer `buf`
+        constexpr int S = decltype(setc)::value;
         const unsigned base = lds0 + (unsigned)buf * ABUF_BYTES;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             unsigned h0, l0, h1, l1;
-            split2(__uint_as_float(araw[j].x), __uint_as_float(araw[j].y), h0, l0);
-            split2(__uint_as_float(araw[j].z), __uint_as_float(araw[j].w), h1, l1);
+            split2(__uint_as_float(araw[S][j].x), __uint_as_float(araw[S][j].y), h0, l0);
+            split2(__uint_as_float(araw[S][j].z), __uint_as_float(araw[S][j].w), h1, l1);
             write_planes(base + apw[j], h0, h1, l0, l1);
         }
     };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, NA - 1> I1;      // the second set (the first one again without DEEP)
+    typedef std::integral_constant<int, VMW> IW;
+    typedef std::integral_constant<int, 4> I4;
 
     // ---- fragment read offsets (k-step 0 of a stage; k-step 1 = ^ 32) ----
     const int fr = lane & 31, fh = lane >> 5;
@@ -176,67 +211,91 @@ __global__ __launch_bounds__(THREADS) void gemm_x3c_kernel(DmaGemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto multiply = [&](int cur) {                // the step's 48 MFMAs on A buffer `cur`, W stage `cur`
-        const unsigned ab = lds0 + (unsigned)cur * ABUF_BYTES, wb = lds0 + (unsigned)cur * WSTAGE_BYTES;
+    // one 16-deep half of a step: 24 MFMAs on A buffer `cur`, W stage `wst`; `mem(0)` runs behind the first twelve, `mem(1)`
+    // behind the last twelve.  The step's eight memory instructions are issued there, two at a time: a wave that issues
+    // them in one burst at the step's start sits in the issue queue of a saturated memory pipeline (the no-MFMA variant
+    // of this kernel needs 1.5 us per step for its 64 KB) with NO MFMA of its own in flight -- measured: MFMA time and
+    // memory time added up exactly (2.9 us per step); behind twelve MFMAs (384 pipe cycles) a blocked issue costs nothing.
+    auto multiply_half = [&](int cur, int wst, int ks, auto&& mem) {
+        const unsigned ab = lds0 + (unsigned)cur * ABUF_BYTES, wb = lds0 + (unsigned)wst * WSTAGE_BYTES;
+        Frag f;
+        const unsigned x = ks ? 32u : 0u;
+        read_frags(f, (ab + offA[0]) ^ x, (ab + offA[1]) ^ x, (ab + offA[2]) ^ x, (ab + offA[3]) ^ x, (wb + offB[0]) ^ x, (wb + offB[1]) ^ x);
+        wait_frags(f);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            Frag f;
-            const unsigned x = ks ? 32u : 0u;
-            read_frags(f, (ab + offA[0]) ^ x, (ab + offA[1]) ^ x, (ab + offA[2]) ^ x, (ab + offA[3]) ^ x, (wb + offB[0]) ^ x, (wb + offB[1]) ^ x);
-            wait_frags(f);
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, f.ah[i]), al = __builtin_bit_cast(bf16x8_t, f.al[i]);
-                    const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, f.bh[j]), bl = __builtin_bit_cast(bf16x8_t, f.bl[j]);
-                    if (!FEED && (diag & 2)) { asm volatile("" :: "v"(ah), "v"(al), "v"(bh), "v"(bl)); continue; }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
-                }
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, f.ah[i]), al = __builtin_bit_cast(bf16x8_t, f.al[i]);
+                const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, f.bh[j]), bl = __builtin_bit_cast(bf16x8_t, f.bl[j]);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
+            }
+            if (i & 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                mem(i >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
 
-    // ---- prologue: A planes of the first step, W stage of the first step, A registers of the second ----
-    load_a(kt0);
+    // ---- prologue: A planes of the first step, W stage(s) ahead, A registers of the following step(s) ----
+    load_a(kt0, I0{});
     issue_w(kt0, 0);
-    asm volatile("s_waitcnt vmcnt(4)" : "+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[3]) :: "memory");   // the A loads (older) are in
-    convert_a(0);
-    load_a(kt0 + 1);
-    asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");        // W stage 0 landed (my pieces), my plane stores done
+    wait_a(I0{}, I4{});                           // the A loads (older than the 4 W pieces) are in
+    convert_a(0, I0{});
+    if (DEEP) {
+        load_a(kt0 + 1, I1{});
+        issue_w(kt0 + 1, 1);
+        load_a(kt0 + 2, I0{});
+        asm volatile("s_waitcnt vmcnt(12)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");    // W stage 0 landed (my pieces), my plane stores done
+    } else {
+        load_a(kt0 + 1, I0{});
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        __builtin_amdgcn_sched_barrier(0);
-        issue_w(kt + 1, cur ^ 1);                 // the stage everybody finished reading before the barrier just passed
+    // one 32-deep step; SET = the register set that holds the A rows of step kt + 1.  In flight when the step starts,
+    // oldest first: [A(kt+1)] [W(kt+1)] [A(kt+2)] (DEEP) / [A(kt+1)] (else); every step issues its W pieces FIRST, then its A loads
+    typedef std::integral_constant<int, VMX> IX;
+    typedef std::integral_constant<int, 1> H1;
+    auto step = [&](const int kt, auto setc) {
+        const int rel = kt - kt0, cur = rel & 1, wst = rel % NW;
+        const int kw = kt + NW - 1, sw = (rel + NW - 1) % NW;      // the W step issued now, into the stage everybody finished reading before the barrier just passed
+        auto mem_w = [&](int half) { issue_w2(kw, sw, half); };                                   // W pieces: hi plane, then lo plane
+        auto mem_a = [&](int half) { if (half == 0) load_a2(kt + NA + 1, setc, I0{}); else load_a2(kt + NA + 1, setc, H1{}); };
         __builtin_amdgcn_sched_barrier(0);
         if (w < 4) {
-            // outstanding, oldest first: A loads of step kt + 1 (4), the W pieces just issued (4)
-            if (FEED || !(diag & 1))
-            asm volatile("s_waitcnt vmcnt(4)" : "+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[3]) :: "memory");
-            convert_a(cur ^ 1);
-            load_a(kt + 2);
+            // in flight, oldest first: [A(kt+1)] [W(kt+1)] [A(kt+2)] (DEEP) / [A(kt+1)]
+            wait_a(setc, IX{});
+            convert_a(cur ^ 1, setc);
             __builtin_amdgcn_sched_barrier(0);
-            multiply(cur);
+            multiply_half(cur, wst, 0, mem_w);
+            multiply_half(cur, wst, 1, mem_a);
         } else {
-            multiply(cur);
+            multiply_half(cur, wst, 0, mem_w);
             __builtin_amdgcn_sched_barrier(0);
-            if (FEED || !(diag & 1))
-            asm volatile("s_waitcnt vmcnt(4)" : "+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[3]) :: "memory");
-            convert_a(cur ^ 1);
-            load_a(kt + 2);
+            wait_a(setc, IW{});          // .. plus the four W pieces just issued
+            convert_a(cur ^ 1, setc);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply_half(cur, wst, 1, mem_a);
         }
         __builtin_amdgcn_sched_barrier(0);
-        // my W pieces of step kt + 1 have landed (the 4 A loads behind them may still fly), my plane stores are done
-        if (FEED || !(diag & 1)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // my W pieces of step kt + 1 have landed (what was issued behind them may still fly), my plane stores are done
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VMW) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    };
+    for (int kt = kt0; kt < kt1; kt += 2) {
+        step(kt, I1{});                           // A(kt + 1) sits in the second set on even steps (the only set without DEEP)
+        if (kt + 1 < kt1) step(kt + 1, I0{});
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[3]) :: "memory");   // the loads of the step behind the last one (discarded)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the loads of the steps behind the last one (discarded)
+    asm volatile("" : "+v"(araw[0][0]), "+v"(araw[0][1]), "+v"(araw[0][2]), "+v"(araw[0][3]));
+    asm volatile("" : "+v"(araw[NA - 1][0]), "+v"(araw[NA - 1][1]), "+v"(araw[NA - 1][2]), "+v"(araw[NA - 1][3]));
 
     if (FEED && qpart >= 0) {
         // one quarter of a split tile: park the accumulators (thread-major: a wave instruction stores 256 contiguous
@@ -498,7 +557,7 @@ int pgasr_internal_x3c_launch(const PgasrX3cArgs& a, hipStream_t st) {
     DmaGemmArgs g{a.A, a.Whi, a.Wlo, a.C, a.M, a.N, a.K, a.lda, a.ldc, a.bias, a.dact_y, a.slope,
                   a.queue, a.xcc_busy, a.tiles_done, a.mt_count, a.nt_count, a.order, a.quarters, a.split_tiles, a.slabs, a.arrive};
     if (!a.feed) {
-        const size_t lds = (size_t)c256::LDS_BYTES;
+        const size_t lds = (size_t)c256::LDS_BYTES_DEEP;
         if (hipFuncSetAttribute((const void*)c256::gemm_x3c_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PGASR_ERR_LAUNCH;
         PGASR_LAUNCH_KERNEL(c256::gemm_x3c_kernel<false>, dim3((unsigned)(a.N / c256::TN), (unsigned)((a.M + c256::TM - 1) / c256::TM)), dim3(c256::THREADS), lds, st, g);

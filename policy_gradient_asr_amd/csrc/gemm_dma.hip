@@ -678,7 +678,7 @@ extern "C" int pgasr_gemm_x3w_f32(int M, int N, int K, const float* A, int lda, 
     if (gy > 65535u) return PGASR_ERR_UNSUPPORTED;
     if ((size_t)M * ldc * 4 >= ((size_t)1 << 32)) return PGASR_ERR_UNSUPPORTED;      // buffer-addressed epilogue (callers fall back to pgasr_gemm_f32)
     if (N % 256 == 0 && x3w_tile_mode(false) == 2 && (size_t)M * lda * 4 < ((size_t)1 << 32)) {
-        PgasrX3cArgs a{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, dact_y, slope, 0, nullptr, nullptr, nullptr, 0, 0, 0, x3w_diag(), 0, nullptr, nullptr};
+        PgasrX3cArgs a{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, dact_y, slope, 0, nullptr, nullptr, nullptr, 0, 0, 0, 1, 0, nullptr, nullptr};
         return pgasr_internal_x3c_launch(a, (hipStream_t)stream);
     }
     if (N % w256::TN == 0 && x3w_tile_mode(false) == 1) {     // the 256 x 256 / 4-wave tile (one accumulation chain over K per tile)

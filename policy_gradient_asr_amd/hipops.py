@@ -206,14 +206,16 @@ def pg_loss_value(log_probs, path, input_lengths, nll, utt_scale, pg_coef):
     return terms
 
 
-def frame_argmax_sample(scores, seed=0, offset=0, want_greedy=True, want_sample=True):
+def frame_argmax_sample(scores, seed=0, offset=0, want_greedy=True, want_sample=True, batch_stride=0, batch_offset=0):
+    """batch_stride / batch_offset: the GLOBAL batch and this shard's first utterance in it (data parallel: N ranks with
+    one seed then draw what one process holding the whole batch draws); 0 / 0 = the local batch is the whole batch."""
     lib = _lib.load()
     _req(scores, torch.float32, "scores")
     T, B, V = scores.shape
     g = torch.empty(T, B, dtype=torch.int32, device=scores.device) if want_greedy else None
     s = torch.empty(T, B, dtype=torch.int32, device=scores.device) if want_sample else None
     st = lib.pgasr_frame_argmax_sample(_p(scores), T, B, V, int(seed) & (2 ** 64 - 1), int(offset) & 0xFFFFFFFF,
-                                       _p(g), _p(s), _stream())
+                                       int(batch_stride), int(batch_offset), _p(g), _p(s), _stream())
     _lib.check(st, "pgasr_frame_argmax_sample")
     return g, s
 

@@ -49,7 +49,7 @@ class PGCTCLossFn(torch.autograd.Function):
     unit_seed_ptr = None
     unit_hits = 0              # how often the shortcut was taken (tests)
     @staticmethod
-    def forward(ctx, logits, in_len, targets, tg_len, lam, seed, offset, global_batch, blank, beam=0):
+    def forward(ctx, logits, in_len, targets, tg_len, lam, seed, offset, global_batch, blank, beam=0, sample_base=-1):
         T, B, V = logits.shape
         dev = logits.device
         lp = hipops.log_softmax_rows(logits.contiguous())
@@ -60,17 +60,19 @@ class PGCTCLossFn(torch.autograd.Function):
         main = torch.cuda.current_stream()
         side = PGCTCLossFn._lattice_streams.setdefault(main.cuda_stream, None) or streams.side_stream("loss_section")
         PGCTCLossFn._lattice_streams[main.cuda_stream] = side
+        # sample_base >= 0: this shard's first utterance in the GLOBAL batch -- the draws are then addressed globally
+        lay = {"batch_stride": int(global_batch), "batch_offset": int(sample_base)} if sample_base >= 0 else {}
         side.wait_stream(main)
         with torch.cuda.stream(side):
             if beam > 0:
                 # baseline hypothesis = prefix beam search + collapse_fn (policy_grad.py:6-8), rows [0] of the pair buffers
-                _, sample = hipops.frame_argmax_sample(lp, seed=seed, offset=offset, want_greedy=False)
+                _, sample = hipops.frame_argmax_sample(lp, seed=seed, offset=offset, want_greedy=False, **lay)
                 tokens = torch.zeros(2, B, T, dtype=torch.int32, device=dev)
                 tok_len = torch.empty(2, B, dtype=torch.int32, device=dev)
                 hipops.ctc_beam_search(lp, in_len, beam=beam, blank=blank, collapse=True, out=(tokens[0], tok_len[0]))
                 hipops.ctc_collapse(sample[None], in_len, blank=blank, out=(tokens[1:], tok_len[1:]))
             else:
-                greedy, sample = hipops.frame_argmax_sample(lp, seed=seed, offset=offset)
+                greedy, sample = hipops.frame_argmax_sample(lp, seed=seed, offset=offset, **lay)
                 paths = torch.stack((greedy, sample), dim=0)                          # (2,T,B)
                 tokens, tok_len = hipops.ctc_collapse(paths, in_len, blank=blank)     # (2,B,T), (2,B)
             dist = hipops.edit_distance(targets.repeat(2, 1), tg_len.repeat(2), tokens.view(2 * B, T), tok_len.view(2 * B))
@@ -91,15 +93,17 @@ class PGCTCLossFn(torch.autograd.Function):
         (grad,) = ctx.saved_tensors
         if PGCTCLossFn.unit_seed_ptr is not None and g.data_ptr() == PGCTCLossFn.unit_seed_ptr and g.numel() == 1:
             PGCTCLossFn.unit_hits += 1
-            return grad, None, None, None, None, None, None, None, None, None
-        return grad * g, None, None, None, None, None, None, None, None, None
+            return grad, None, None, None, None, None, None, None, None, None, None
+        return grad * g, None, None, None, None, None, None, None, None, None, None
 
 
-def pg_ctc_loss(logits, in_len, targets, tg_len, lam=1.0, seed=0, offset=0, global_batch=None, blank=0, beam=0):
-    """beam > 0: the baseline reward comes from the prefix-beam-search hypothesis of that width (see PGCTCLossFn)."""
+def pg_ctc_loss(logits, in_len, targets, tg_len, lam=1.0, seed=0, offset=0, global_batch=None, blank=0, beam=0, sample_base=-1):
+    """beam > 0: the baseline reward comes from the prefix-beam-search hypothesis of that width (see PGCTCLossFn).
+    sample_base >= 0 (data parallel): index of this shard's first utterance in the global batch; the sampled paths are
+    then those of the single-process global batch with the same seed."""
     B = logits.shape[1]
     return PGCTCLossFn.apply(logits, in_len, targets, tg_len, float(lam), int(seed), int(offset),
-                             int(global_batch or B), int(blank), int(beam))
+                             int(global_batch or B), int(blank), int(beam), int(sample_base))
 
 
 class CTCLoss(nn.Module):

@@ -233,7 +233,11 @@ class PolicyGradientTrainer(DataParallelStep):
             raise ValueError("reward_decoder must be 'greedy' or 'beam'")
         self.reward_decoder, self.beam_size = reward_decoder, int(beam_size)
         self.lam = lam
-        self.seed = seed + 7919 * rank     # independent sample streams per rank
+        # ONE sampling seed for all ranks: a rank addresses its draws by GLOBAL utterance index (contiguous shards: rank *
+        # local batch), so N ranks sample exactly the paths of one process holding the whole batch -- the N-rank REINFORCE
+        # gradient equals the single-process one, like the CTC part (tests/test_dp_rccl_gpu.py, lambda = 1)
+        self.seed = seed
+        self.rank = rank
         if hasattr(model, "encoder"):
             model.encoder.dropout_seed = 0x5EED + 104729 * rank
         self.blank = blank
@@ -326,6 +330,7 @@ class PolicyGradientTrainer(DataParallelStep):
         logits, in_len = self.model.logits(x, fmask, in_len)
         loss, nll, R_s, R_g = pg_ctc_loss(logits, in_len, tg, tg_len, lam=self.lam, seed=self.seed,
                                           offset=self.nstep + 1, global_batch=global_batch, blank=self.blank,
-                                          beam=self.beam_size if self.reward_decoder == "beam" else 0)
+                                          beam=self.beam_size if self.reward_decoder == "beam" else 0,
+                                          sample_base=self.rank * x.shape[0] if self.world > 1 else -1)
         self.last_stats = (nll, R_s, R_g)
         return loss

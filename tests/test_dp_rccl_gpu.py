@@ -37,9 +37,10 @@ def test_two_rank_rccl_step_matches_single_process_global_batch(tmp_path, lam):
     assert all(r["world"] == world for r in res)
     assert torch.equal(res[0]["flat"], res[1]["flat"])                 # replicas bit-identical after two steps
     assert torch.equal(res[0]["gflat"], res[1]["gflat"])               # both hold the all-reduced gradient
-    if lam == 0.0:
-        # deterministic objective: compare with one process holding the whole batch (sampled paths are seeded per rank,
-        # so the lambda = 1 run is checked for replica identity and finiteness only)
+    if True:
+        # compare with ONE process holding the whole batch -- for lambda = 1 too: all ranks share the sampling seed and
+        # address their draws by global utterance index (pgasr_frame_argmax_sample ctr_stride / ctr_base), so the sampled
+        # paths, the rewards and the REINFORCE term of the two shards are those of the global batch
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import dp_rccl_worker as w
         dev = torch.device("cuda", 0)

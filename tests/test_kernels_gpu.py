@@ -276,3 +276,22 @@ def test_batch_prep_matches_torch(ops, dev):
     in_len, tg_len, tg32 = ops.batch_prep(fmask.to(dev), tmask.to(dev), targets.to(dev))
     assert in_len.dtype == tg_len.dtype == tg32.dtype == torch.int32
     assert torch.equal(in_len.cpu(), lens.int()) and torch.equal(tg_len.cpu(), tl.int()) and torch.equal(tg32.cpu(), targets.int())
+
+
+def test_sampler_draws_are_addressed_globally_across_shards():
+    """Data parallel (model.py:201): a rank samples utterances [base, base + B_local) of a global batch of `stride` with
+    the SAME seed and gets exactly the paths a single process holding the whole batch samples for them."""
+    from policy_gradient_asr_amd import hipops as ops
+    T, Bg, V = 37, 12, 29
+    g = torch.Generator().manual_seed(3)
+    scores = torch.randn(T, Bg, V, generator=g).to("cuda:0")
+    _, whole = ops.frame_argmax_sample(scores, seed=99, offset=7, want_greedy=False)
+    for base, nb in ((0, 4), (4, 4), (8, 4), (0, 12), (5, 7)):
+        shard = scores[:, base:base + nb].contiguous()
+        _, part = ops.frame_argmax_sample(shard, seed=99, offset=7, want_greedy=False, batch_stride=Bg, batch_offset=base)
+        assert torch.equal(part, whole[:, base:base + nb])
+    _, local = ops.frame_argmax_sample(scores[:, 4:8].contiguous(), seed=99, offset=7, want_greedy=False)
+    assert not torch.equal(local, whole[:, 4:8])          # without the layout a shard draws its own (local) counters
+    import pytest
+    with pytest.raises(Exception):
+        ops.frame_argmax_sample(scores[:, :4].contiguous(), seed=1, want_greedy=False, batch_stride=6, batch_offset=4)   # base + B > stride
