@@ -440,6 +440,13 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_base) {
 // k-steps x 3 split terms); the four partial tiles are summed through LDS and each compute thread
 // finishes ONE (unit, utterance) cell.
 // exchange slot per cluster: [parity 2][kc 32][n 16][plane NP][8 bf16]; member g owns kc = 2g, 2g+1.
+// Measured and NOT kept (round 3, commit "second forward-sweep structure" in the history): the polled h_{t-1} itself through
+// LDS instead of the partial tiles -- every wave copies its validated k-quarter into an LDS image, one barrier, every wave
+// reads the whole 16 KB and multiplies all 256 k into its OWN 16 gate rows, so that the 16 x 16 MFMA output hands each lane
+// the four gates of one cell and the 4-way partial sum (16 KB of ds_write_b128, 4 reads + adds per cell) disappears.  Correct
+// (all BLSTM tests, both precisions), but 1.22 ms per sweep against 1.05, with one accumulator chain and with four: the
+// K-split's MFMAs run BEFORE the barrier, i.e. under the spread of the four waves' poll completions; behind the barrier all
+// 24 of them (and 16 fragment reads) are serial time on the chain.
 // ------------------------------------------------------------------------------------------
 template <int NP>
 __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
