@@ -32,7 +32,8 @@ import torch.distributed as dist  # noqa: E402
 
 B_PER_GPU, T, F, V, L = 32, 1000, 80, 29, 100
 METRIC = "utterances/sec (B=32,T=1000,F=80) policy-grad step, 1/2/4/8 MI355X"
-DTYPE = "bf16x3 (fp32 storage and accumulate; every dense product = 3 bf16 MFMA terms hi*hi+hi*lo+lo*hi of a 2-plane split)"
+DTYPE = ("bf16x3 (fp32 storage and accumulate; every dense product = 3 bf16 MFMA terms hi*hi+hi*lo+lo*hi of a 2-plane split; the "
+         "fp32-faithful variant of the same step -- exact fp32 MFMA GEMMs, 3-plane / 6-product sweeps -- is timed beside it: precision_variants.f32)")
 BF16_DENSE_PEAK_TF = 2500.0       # MI355X_MICROARCH.md, dense
 FP32_MFMA_PEAK_TF = 157.3
 STEP_GFLOP_PER_UTT = 28.65        # dense contraction forward + backward, T=1000
@@ -608,15 +609,17 @@ def main():
         rl = sweep_roofline(prof, n_sampled, sum(frames) / len(frames))
         name, avg_ms, achieved, peak, flops_per_launch = rl["kernel"], rl["avg_launch_ms"], rl["achieved"], rl["peak"], rl["flops_per_launch"]
         traffic, traffic_src = None, None         # HBM bytes per launch of that kernel from the committed PMC passes
-        for fname in ("r02_pmc.json", "r01_pmc.json"):     # written by tools/pmc_summary.py
-            try:
-                with open(os.path.join(ROOT, "profiles", fname)) as fi:
-                    traffic = json.load(fi)["kernels"][name]["hbm_bytes_per_launch"]
-                traffic_src = f"from_committed_profile profiles/{fname} (separate --pmc passes; the profiler serialises kernels, " \
-                              "so that pass ran the sequential order of the same kernels)"
-                break
-            except Exception:  # noqa: BLE001 - the file is optional evidence, never required to run
-                traffic = None
+        try:       # written by tools/pmc_summary3.py; the file is optional evidence, never required to run
+            with open(os.path.join(ROOT, "profiles", "r03_pmc.json")) as fi:
+                rec = json.load(fi)["fed_sweeps"]["kernels"][name]
+            traffic = rec["hbm_bytes_per_launch"]
+            traffic_src = ("from_committed_profile profiles/r03_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
+                           "gfx950 FETCH x2 correction) on the FED sweep kernels of the timed step with their producer GEMM run first "
+                           "(a counter pass serialises kernels; tools/dev/tools_fed_sweep.py); read %.0f MB + write %.0f MB per launch "
+                           "against 262 + 392 MB (forward sweep) / 392 + 262 MB (backward sweep) algorithmic"
+                           % (rec["hbm_read_bytes_per_launch"] / 1e6, rec["hbm_write_bytes_per_launch"] / 1e6))
+        except Exception:  # noqa: BLE001
+            traffic = None
         gflop_step_gpu = STEP_GFLOP_PER_UTT * (sum(frames) / len(frames) / T)     # per GPU: 28.65 GFLOP per 1000 frames
         step_tf = gflop_step_gpu / (ms * 1e-3) / 1e3
         out = {
