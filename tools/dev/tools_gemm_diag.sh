@@ -16,7 +16,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
            "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_EA0_RDREQ_sum" "TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "TA_BUSY_avr TCP_TA_DATA_STALL_CYCLES_sum"; do
   i=$((i+1))
-  rm -rf "$O/r03_gemm_pmc$i"
   REPS=2 PGASR_X3W_TILE=256 timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d "$O/r03_gemm_pmc$i" -- python3 "$R/tools/dev/tools_gemm3.py" > "$O/r03_gemm_pmc$i.log" 2>&1 || echo "pass $i failed"
 done
 echo "diag done"

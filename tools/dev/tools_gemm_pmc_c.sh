@@ -10,7 +10,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
            "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_EA0_RDREQ_sum" "TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
   i=$((i+1))
-  rm -rf "$O/${TAG}_pmc$i"
   WHICH=nt,nn REPS=2 timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d "$O/${TAG}_pmc$i" -- python3 "$R/tools/dev/tools_gemm3.py" > "$O/${TAG}_pmc$i.log" 2>&1 || echo "pass $i failed"
 done
 python3 - <<PY
