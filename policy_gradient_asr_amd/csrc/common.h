@@ -73,6 +73,7 @@ struct PgasrTn256Args {
     float alpha;
     unsigned* queue;            // zeroed word: work items are drawn from it (queue mode), or nullptr (item = blockIdx.x)
     const unsigned* xcc_busy;   // queue mode: workgroups on an XCD whose word is non-zero take no item
+    int diag;                   // diagnostic variants (PGASR_TN_DIAG, results invalid): bit 0 no loads / conversion in the loop, bit 1 no MFMA phase
 };
 bool pgasr_internal_tn256_ok(const PgasrTn256Args& a);
 int pgasr_internal_tn256_launch(PgasrTn256Args a, int masked_then_unmasked, hipStream_t st);

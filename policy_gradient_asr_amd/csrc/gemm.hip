@@ -709,7 +709,7 @@ static int gemm_launch(GemmArgs& g, int transA, int transB, int sum_batches, int
     bool done_tn256 = false;
     if (precision == 1 && transA && !transB && use_partial && g.norm_operand == 0) {
         PgasrTn256Args t{g.A, g.B, g.partial, g.M, g.N, g.K, g.lda, g.ldb, g.sA, g.sB, g.batch, g.splitk, g.kper, g.alpha,
-                         queue_mode ? g.queue : nullptr, queue_mode ? g.xcc_busy : nullptr};
+                         queue_mode ? g.queue : nullptr, queue_mode ? g.xcc_busy : nullptr, getenv("PGASR_TN_DIAG") ? atoi(getenv("PGASR_TN_DIAG")) : 0};
         if (pgasr_internal_tn256_ok(t)) {
             const int st_ = pgasr_internal_tn256_launch(t, queue_mode ? 1 : 0, st);
             if (st_ != PGASR_OK) return st_;

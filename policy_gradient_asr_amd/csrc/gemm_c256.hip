@@ -439,7 +439,13 @@ __global__ __launch_bounds__(THREADS) void gemm_t256_kernel(PgasrTn256Args g) {
         item = *mailbox;
         __syncthreads();
     } else {
-        item = blockIdx.x;
+        // plain launch: workgroups are dealt round-robin over the 8 XCDs (observed, speed only), so workgroup b shares an L2
+        // with b + 8, b + 16, ..: give every XCD WHOLE K-slabs -- the tiles of a slab read the same k-rows (an A byte is
+        // read by N/256 of them, a B byte by M/256), and side by side behind one L2 they fetch them from HBM once
+        const unsigned per = (unsigned)(tx * ty), nslab = (unsigned)(g.batch * g.splitk);
+        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        const unsigned zz = xcd + 8u * (j / per);
+        item = (nitems % (8u * per) == 0u && nslab % 8u == 0u) ? zz * per + j % per : blockIdx.x;
     }
     if (item >= nitems) return;
     // items of one K-slab are adjacent: they run at the same time and share the slab's rows in L2 / MALL
@@ -516,16 +522,14 @@ __global__ __launch_bounds__(THREADS) void gemm_t256_kernel(PgasrTn256Args g) {
     T256_BARRIER();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
+        const bool mem = !(g.diag & 1), mul = !(g.diag & 2);
         if (w < 4) {
-            if (kt + 1 < nk) convert(cur ^ 1);
-            load(kt + 2);
-            multiply(cur, 0);
-            multiply(cur, 1);
+            if (mem) { if (kt + 1 < nk) convert(cur ^ 1); load(kt + 2); }
+            if (mul) { multiply(cur, 0); multiply(cur, 1); }
         } else {
-            multiply(cur, 0);
-            if (kt + 1 < nk) convert(cur ^ 1);
-            load(kt + 2);
-            multiply(cur, 1);
+            if (mul) multiply(cur, 0);
+            if (mem) { if (kt + 1 < nk) convert(cur ^ 1); load(kt + 2); }
+            if (mul) multiply(cur, 1);
         }
         T256_BARRIER();
     }
