@@ -37,7 +37,7 @@ typedef enum pgasr_status {
     PGASR_ERR_TIMEOUT = 5        /* a bounded in-kernel wait gave up (persistent LSTM) */
 } pgasr_status;
 
-#define PGASR_ABI_VERSION 3
+#define PGASR_ABI_VERSION 4
 
 int pgasr_abi_version(void);
 const char* pgasr_status_string(int status);
@@ -214,6 +214,26 @@ int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int lda, const 
                             const unsigned* xcc_busy, unsigned* tiles_done, int order, int phase, int head_groups,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* The two weight-gradient products of one BLSTM layer (model.py:39-44; torch autograd's dW_ih, dW_hh) in ONE queue-mode
+ * launch of the 256 x 256 TN kernel:
+ *   dwih_perm (2*4H x in_dim) = dgates^T x                   (K = T*B rows of the (t, b)-major tensors)
+ *   dwhh_perm (2 x 4H x H)    = dgates[d]^T h_prev(d)        (K = (T-1)*B rows; prev = t-1 for d = 0, t+1 for d = 1; h = out)
+ * bf16x3 arithmetic (as pgasr_gemm_f32 precision 1); every 256 x 256 tile is the sum of its partial products over the time
+ * slabs of pgasr_lstm_wgrad_slabs(T) in the order a backward sweep completes them (direction 0: [h_j, h_j+1) from the top
+ * down; direction 1: the mirror image) -- a function of the shapes only, so every mode gives the same bits.
+ * slab_done != NULL: dgates belongs to a backward sweep that is STILL RUNNING (pgasr_lstm_layer_bwd_streamed on another
+ * stream, launched before this call); the work items then wait for the slab_done words that cover their rows and read
+ * dgates with agent-scope loads.  slab_done == NULL: dgates is complete (the sequential order, same bits).
+ * xcc_busy (optional): the sweep's busy counters (workgroups on its XCDs take no item; a second unmasked launch picks up
+ * any rest).  err_word (optional): set to 1 when a wait gives up after 3 s -- pass the sweep workspace's error word.
+ * Needs in_dim % 256 == 0, B % 32 == 0, T >= 2 and 16-byte aligned tensors, else PGASR_ERR_UNSUPPORTED (use pgasr_gemm_f32
+ * behind the sweep). */
+size_t pgasr_lstm_wgrads_workspace_bytes(int T, int in_dim);
+int pgasr_lstm_wgrads_streamed(const float* dgates, const float* x, const float* out, int T, int B, int in_dim,
+                               float* dwih_perm, float* dwhh_perm, const unsigned* xcc_busy,
+                               const unsigned* slab_done, int* err_word,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 size_t pgasr_colsum_workspace_bytes(int rows, int cols);
 int pgasr_colsum_f32(const float* X, int rows, int cols, int ld, float* out, float* out2, int accumulate,
                      void* workspace, size_t workspace_bytes, void* stream);
@@ -283,6 +303,10 @@ int pgasr_lstm_busy_offset(int B, int backward, size_t* offset);   /* 8 per-XCD 
  * GEMMs that are to run BESIDE a sweep, so that the sweep's workgroups are dispatched first (a large grid
  * enqueued ahead of the sweep delays it by the whole GEMM).  A hint only: never affects results. */
 int pgasr_stream_gate(const unsigned* words, int count, int timeout_us, void* stream);
+/* The same for consumers that WAIT for the sweep (pgasr_lstm_wgrads_streamed): holds `stream` until the counters add up to
+ * `need` = the sweep's clusters, 2 * ceil(B/16) -- all of its workgroups are then resident; workgroups that poll for the
+ * sweep's publications must not take CUs the sweep still needs. */
+int pgasr_stream_gate_sum(const unsigned* words, int count, int need, int timeout_us, void* stream);
 /* One wave on `stream` waits (at most timeout_us <= 1e6) for words[0] != 0 and then writes words[1] = 1 if it saw it, else
  * 0.  Set words[0] from ANOTHER stream after this call: words[1] tells whether the two streams really run concurrently
  * (they do not under kernel-serialising profilers / launch-blocking modes / a single hardware queue).  The fed sweeps
@@ -316,6 +340,24 @@ int pgasr_lstm_layer_bwd_fed(float* gates, const float* out, const float* cbuf, 
 int pgasr_lstm_layer_bwd(float* gates, const float* out, const float* cbuf, const float* dout,
                          const void* whh_pack_bwd, const int32_t* lengths, int T, int B, int flags,
                          float* dbias_part, void* workspace, size_t workspace_bytes, void* stream);
+/* STREAMED backward sweep (round 3): the sweep publishes its progress so that the SAME layer's weight-gradient products
+ * (pgasr_lstm_wgrads_streamed, on another stream, launched after this call) consume its d(pre-activation) rows while it
+ * runs, instead of waiting for its end.  The products are sums over n = pgasr_lstm_wgrad_slabs(T, edges, max) TIME slabs
+ * 0 = h_0 < h_1 < .. < h_n = T (sizes 16, 24, 32, 48, 64, 88, 120, 168, 168 .. frames: small where a sweep ends); sweep step s is
+ * frame T-1-s for direction 0 and frame s for direction 1, so for both directions the sweep steps < T - h_(n-k) complete
+ * the first k slabs of the direction's order.  slab_done[c], c = 2 * (16-utterance group) + direction (2 * ceil(B/16)
+ * words, zeroed by the caller BEFORE this launch), counts those publications k = 1..n: the rows are then in memory and
+ * readable with agent-scope loads from any XCD.  The rows leave the storer waves as ordinary stores; one extra
+ * ("flusher") workgroup per cluster waits until every member's stores of a slab are acknowledged, writes the XCD's L2
+ * back (agent-scope release) and then publishes the count -- nothing on the sweep's dependent chain (measured: 1.4 us
+ * of sweep time per publication).  fed == NULL: dout is complete (as pgasr_lstm_layer_bwd); else as
+ * pgasr_lstm_layer_bwd_fed.  Conditions as for the fed sweeps (pgasr_lstm_fed_ok), else PGASR_ERR_UNSUPPORTED. */
+int pgasr_lstm_wgrad_slabs(int T, int* edges, int max_edges);
+int pgasr_lstm_layer_bwd_streamed(float* gates, const float* out, const float* cbuf, const float* dout,
+                                  const void* whh_pack_bwd, const int32_t* lengths, int T, int B, int flags,
+                                  float* dbias_part, const unsigned* fed, int fed_need, float drop_p, uint64_t drop_seed,
+                                  uint32_t drop_offset, unsigned* slab_done,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A7  CTC prefix beam search (CTCdecoder.py:41-116), one workgroup per utterance.

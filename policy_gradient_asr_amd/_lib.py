@@ -77,6 +77,7 @@ SIGNATURES = {
     "pgasr_lstm_busy_offset": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "pgasr_lstm_status": (C.c_int, [c_ptr, C.c_size_t, C.c_int, C.c_int, c_ptr]),
     "pgasr_stream_gate": (C.c_int, [c_ptr, C.c_int, C.c_int, c_ptr]),
+    "pgasr_stream_gate_sum": (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
     "pgasr_stream_probe": (C.c_int, [c_ptr, C.c_int, c_ptr]),
     "pgasr_lstm_layer_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int,
                                        c_f32p, C.c_float, C.c_uint64, C.c_uint32, c_ptr, C.c_size_t, c_ptr]),
@@ -87,6 +88,13 @@ SIGNATURES = {
                                            c_f32p, c_ptr, C.c_int, C.c_float, C.c_uint64, C.c_uint32, c_ptr, C.c_size_t, c_ptr]),
     "pgasr_lstm_layer_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int,
                                        c_f32p, c_ptr, C.c_size_t, c_ptr]),
+    "pgasr_lstm_wgrad_slabs": (C.c_int, [C.c_int, c_i32p, C.c_int]),
+    "pgasr_lstm_layer_bwd_streamed": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int,
+                                                c_f32p, c_ptr, C.c_int, C.c_float, C.c_uint64, C.c_uint32, c_ptr,
+                                                c_ptr, C.c_size_t, c_ptr]),
+    "pgasr_lstm_wgrads_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "pgasr_lstm_wgrads_streamed": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_ptr,
+                                             c_ptr, c_ptr, c_ptr, C.c_size_t, c_ptr]),
 }
 
 
@@ -114,7 +122,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.pgasr_abi_version() != 3:
+    if lib.pgasr_abi_version() != 4:
         raise PgasrError("libpgasr_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -61,6 +61,31 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// ---- the K-slabs (time ranges) of a BLSTM layer's weight-gradient products (pgasr_lstm_wgrads_streamed) ----
+// Frames 0 = h_0 < h_1 < .. < h_n = T with slab sizes 16, 24, 32, 48, 64, 88, 120, 168, 168, .. (x 11/8, rounded to 8, capped at 168;
+// the last slab takes what is left while that is <= 1.5 sizes).  Direction 0's backward sweep walks DOWN in time, so its tiles use the
+// slabs [h_j, h_j+1) as they are -- the big ones are complete early, the small ones last -- and direction 1's tiles use the mirror
+// image [T - h_j+1, T - h_j).  Either way the slab that is complete after sweep step T - h_j - 1 is the (n - j)-th, so ONE list of
+// publication points P_k = T - h_(n-k), k = 1..n, serves both directions.  Why shrinking slabs: a 256 x 256 tile costs a CU ~3 us per
+// 32 rows (few items in flight: latency bound) while the sweep produces 32 rows in ~1.2 us, so the products run (3 s - 1.2 R) us
+// behind the sweep's end for a slab of s steps with R steps after it: <= ~50 us with these sizes (measured with x 13/8: 112 us;
+// sixteen equal slabs: 185 us).
+// A function of T only -- it DEFINES the summation order of these products in every mode.
+__host__ __device__ inline int pgasr_wslab_next(int s) { const int n = ((s * 11) / 8 + 4) & ~7; return n > 168 ? 168 : n; }
+__host__ __device__ inline int pgasr_wslab_count(int T) {
+    int h = 0, s = 16, n = 1;
+    while (T - h > s + s / 2) { h += s; s = pgasr_wslab_next(s); ++n; }
+    return n;
+}
+__host__ __device__ inline int pgasr_wslab_edge(int T, int i) {     // h_i, i = 0 .. n
+    int h = 0, s = 16;
+    for (int j = 0; j < i; ++j) {
+        if (T - h <= s + s / 2) return T;
+        h += s; s = pgasr_wslab_next(s);
+    }
+    return h;
+}
+
 // ---- internal (not part of the C ABI): the 256 x 256-tile TN product of gemm_dma.hip, reached through pgasr_gemm_f32 ----
 // partial[z][M][N] = alpha * sum_{k in slab(z)} A_b[k][m] * B_b[k][n],  z = b * splitk + s, slab(z) = [s*kper, min(K, (s+1)*kper))
 // bf16x3 arithmetic.  Requirements (checked by pgasr_internal_tn256_ok): M % 256 == 0, N % 256 == 0, K % 32 == 0,
@@ -74,9 +99,16 @@ struct PgasrTn256Args {
     unsigned* queue;            // zeroed word: work items are drawn from it (queue mode), or nullptr (item = blockIdx.x)
     const unsigned* xcc_busy;   // queue mode: workgroups on an XCD whose word is non-zero take no item
     int diag;                   // diagnostic variants (PGASR_TN_DIAG, results invalid): bit 0 no loads / conversion in the loop, bit 1 no MFMA phase
+    // gated mode (queue mode only; gemm_c256.hip): A lies inside the d(pre-activation) tensor of a backward sweep that is still running
+    const unsigned* gate;       // the sweep's slab_done words [2 * gate_nbg] (cluster = 2 * group + direction), or nullptr
+    const float* gate_base;     // row 0, column 0 of that tensor: A's row offset gives the time, the half of the row its columns lie in the direction
+    int gate_T, gate_B, gate_nbg;     // frames, utterances (rows per frame), 16-utterance groups
+    int tslabs;                 // != 0: the K-slabs are the TIME slabs of pgasr_wslab_edge(gate_T, .) (splitk = pgasr_wslab_count(gate_T)), taken in
+                                // the order a backward sweep completes them; A's rows are rows of the tensor at gate_base (gate may be nullptr)
+    int* gate_err;              // set to 1 when a wait gives up (3 s)
 };
 bool pgasr_internal_tn256_ok(const PgasrTn256Args& a);
-int pgasr_internal_tn256_launch(PgasrTn256Args a, int masked_then_unmasked, hipStream_t st);
+int pgasr_internal_tn256_launch(PgasrTn256Args a, int masked_then_unmasked, hipStream_t st, const PgasrTn256Args* second = nullptr);
 
 // ---- internal: the 8-wave 256 x 256 x3w kernel of gemm_c256.hip (cooperative A split), reached through pgasr_gemm_x3w_f32 / _feed_f32 ----
 struct PgasrX3cArgs {

@@ -709,7 +709,8 @@ static int gemm_launch(GemmArgs& g, int transA, int transB, int sum_batches, int
     bool done_tn256 = false;
     if (precision == 1 && transA && !transB && use_partial && g.norm_operand == 0) {
         PgasrTn256Args t{g.A, g.B, g.partial, g.M, g.N, g.K, g.lda, g.ldb, g.sA, g.sB, g.batch, g.splitk, g.kper, g.alpha,
-                         queue_mode ? g.queue : nullptr, queue_mode ? g.xcc_busy : nullptr, getenv("PGASR_TN_DIAG") ? atoi(getenv("PGASR_TN_DIAG")) : 0};
+                         queue_mode ? g.queue : nullptr, queue_mode ? g.xcc_busy : nullptr, getenv("PGASR_TN_DIAG") ? atoi(getenv("PGASR_TN_DIAG")) : 0,
+                         nullptr, nullptr, 0, 0, 0, 0, nullptr};     // no gate, no time slabs
         if (pgasr_internal_tn256_ok(t)) {
             const int st_ = pgasr_internal_tn256_launch(t, queue_mode ? 1 : 0, st);
             if (st_ != PGASR_OK) return st_;
@@ -783,6 +784,55 @@ extern "C" int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float
     g.dact_y = dact_y; g.norm_operand = norm_operand; g.shift = shift; g.scale = scale; g.partial = nullptr;
     g.wide = (((size_t)(M - 1) * ldc + N) * 4 >= ((size_t)1 << 32) || (size_t)M * N * 4 >= ((size_t)1 << 32)) ? 1 : 0;
     return gemm_launch(g, transA, transB, sum_batches, precision, xcc_busy, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// The two weight-gradient products of one BLSTM layer in ONE queue-mode launch of the 256 x 256 TN kernel (gemm_c256.hip):
+//   dwih_perm (2*4H x in_dim)   = dgates^T x                      (K = T*B rows)
+//   dwhh_perm (2 x 4H x H)      = dgates[d]^T h_prev(d)           (K = (T-1)*B rows; prev = t-1 for d = 0, t+1 for d = 1)
+// bf16x3 arithmetic; each 256 x 256 tile is the sum, in the order a backward sweep completes them, of its partial products over the
+// TIME slabs of pgasr_wslab_edge(T, .) (common.h: a function of T only, so every mode gives the same bits).
+// slab_done != NULL: dgates belongs to a backward sweep that is STILL RUNNING (pgasr_lstm_layer_bwd_streamed on another stream,
+// launched before this call); the work items then wait for the slab_done words covering their rows and read dgates with agent-scope loads.
+extern "C" int pgasr_lstm_wgrad_slabs(int T, int* edges, int max_edges) {
+    if (T <= 0) return 0;
+    const int n = pgasr_wslab_count(T);
+    for (int i = 0; edges && i <= n && i < max_edges; ++i) edges[i] = pgasr_wslab_edge(T, i);
+    return n;
+}
+extern "C" size_t pgasr_lstm_wgrads_workspace_bytes(int T, int in_dim) {
+    if (in_dim <= 0 || T <= 0) return 0;
+    return 256 + (size_t)pgasr_wslab_count(T) * ((size_t)2048 * in_dim + (size_t)2 * 1024 * 256) * sizeof(float);
+}
+extern "C" int pgasr_lstm_wgrads_streamed(const float* dgates, const float* x, const float* out, int T, int B, int in_dim,
+                                          float* dwih_perm, float* dwhh_perm, const unsigned* xcc_busy,
+                                          const unsigned* slab_done, int* err_word,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    constexpr int H = 256, G = 2 * 4 * H;
+    if (!dgates || !x || !out || !dwih_perm || !dwhh_perm || T <= 1 || B <= 0 || in_dim <= 0) return PGASR_ERR_INVALID_ARG;
+    const size_t need = pgasr_lstm_wgrads_workspace_bytes(T, in_dim);
+    if (!workspace || workspace_bytes < need) return PGASR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nslab = pgasr_wslab_count(T);
+    float* part_ih = (float*)((char*)workspace + 256);
+    float* part_hh = part_ih + (size_t)nslab * G * in_dim;
+    const long long K_ih = (long long)T * B, K_hh = (long long)(T - 1) * B;
+    if (K_ih >= ((long long)1 << 31)) return PGASR_ERR_UNSUPPORTED;
+    PgasrTn256Args ih{dgates, x, part_ih, G, in_dim, (int)K_ih, G, in_dim, 0, 0, 1, nslab, 0, 1.f,
+                      (unsigned*)workspace, xcc_busy, 0, slab_done, dgates, T, B, (B + 15) / 16, 1, err_word};
+    PgasrTn256Args hh{dgates + (size_t)B * G, out, part_hh, 4 * H, H, (int)K_hh, G, 2 * H, (long long)4 * H - (long long)B * G,
+                      (long long)B * 2 * H + H, 2, nslab, 0, 1.f,
+                      (unsigned*)workspace, xcc_busy, 0, slab_done, dgates, T, B, (B + 15) / 16, 1, err_word};
+    if (!pgasr_internal_tn256_ok(ih) || !pgasr_internal_tn256_ok(hh)) return PGASR_ERR_UNSUPPORTED;
+    if (hipMemsetAsync(workspace, 0, 256, st) != hipSuccess) return PGASR_ERR_LAUNCH;
+    const int rc = pgasr_internal_tn256_launch(ih, 1, st, &hh);
+    if (rc != PGASR_OK) return rc;
+    PGASR_LAUNCH_KERNEL(gemm_reduce_kernel, dim3((unsigned)(((size_t)G * in_dim + 255) / 256), 1), dim3(256), 0, st,
+                       part_ih, nslab, G, in_dim, dwih_perm, in_dim, (long long)0, (const float*)nullptr, (const float*)nullptr, 0, 0.f, 0);
+    PGASR_CHECK_LAUNCH();
+    PGASR_LAUNCH_KERNEL(gemm_reduce_kernel, dim3((unsigned)(((size_t)4 * H * H + 255) / 256), 2), dim3(256), 0, st,
+                       part_hh, nslab, 4 * H, H, dwhh_perm, H, (long long)4 * H * H, (const float*)nullptr, (const float*)nullptr, 0, 0.f, 0);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
 }
 
 extern "C" size_t pgasr_colsum_workspace_bytes(int rows, int cols) {

@@ -417,28 +417,50 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned short* p) {
     return __builtin_bit_cast(bf16x8_t, (s16x8_t){a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w});
 }
 
-__global__ __launch_bounds__(THREADS) void gemm_t256_kernel(PgasrTn256Args g) {
+// GATED: operand A is the d(pre-activation) tensor of a backward LSTM sweep that is STILL RUNNING on other XCDs
+// (pgasr_lstm_layer_bwd_streamed).  Queue mode only.  The K-slabs (time ranges) are visited in the order in which the sweep
+// completes them -- direction 1 walks time upwards, direction 0 downwards; an item's direction is the half of the tensor's row its
+// A columns lie in -- and before its first load an item waits until the sweep's slab_done words cover its rows.  A is then read
+// with agent-scope (sc1) loads: the rows were written back to memory by the producer's L2, this XCD's L2 may still hold lines of
+// an earlier tenant of the same addresses.  Every item computes exactly what the plain kernel computes for the same slab, so the
+// result has the same bits; the wait is bounded (gate_err).
+// Two products in one queue-mode launch (g1.M > 0; same splitk): a layer's dW_ih and dW_hh share the sweep they wait for, and as
+// two launches on one stream the second would start when the first has seen the sweep's LAST slab.  Items are dealt slab by slab:
+// the tiles of product 0's slab j, then those of product 1's slab j.
+template <bool GATED>
+__global__ __launch_bounds__(THREADS) void gemm_t256_kernel(PgasrTn256Args g0, PgasrTn256Args g1) {
     extern __shared__ __attribute__((aligned(128))) unsigned short S[];      // the ONLY LDS object: [buffer][A hi, A lo, B hi, B lo][k][PITCH]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 2, wn = w & 3;
-    if (g.queue && g.xcc_busy) {
+    if (g0.queue && g0.xcc_busy) {
         const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;
-        if (__hip_atomic_load(g.xcc_busy + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+        if (__hip_atomic_load(g0.xcc_busy + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     }
-    const int tx = g.N / TN, ty = g.M / TM;
-    const unsigned nitems = (unsigned)(tx * ty) * (unsigned)(g.batch * g.splitk);
+    const unsigned per0 = (unsigned)((g0.N / TN) * (g0.M / TM) * g0.batch), per1 = g1.M > 0 ? (unsigned)((g1.N / TN) * (g1.M / TM) * g1.batch) : 0u;
+    const unsigned nitems_all = (per0 + per1) * (unsigned)g0.splitk;
     // lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3 of the group's 4 x 16 block; groups 0,1 take
     // columns 0-15 / 16-31 of k 0-7, groups 2,3 the same columns of k 8-15 (= the 32x32x16 operand map)
     const int tro = (8 * (lane >> 5) + ((lane & 15) >> 2)) * PITCH + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   for (;;) {
     unsigned item;
-    if (g.queue) {
+    bool second = false;
+    if (g0.queue) {
         unsigned* mailbox = reinterpret_cast<unsigned*>(S);       // the buffers are idle between two items
-        if (tid == 0) *mailbox = __hip_atomic_fetch_add(g.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) *mailbox = __hip_atomic_fetch_add(g0.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        item = *mailbox;
+        item = (unsigned)__builtin_amdgcn_readfirstlane((int)*mailbox);      // wave-uniform for the compiler too (scalar address arithmetic)
         __syncthreads();
-    } else {
+        if (item >= nitems_all) return;
+        if (per1) {
+            const unsigned jj = item / (per0 + per1), r = item % (per0 + per1);
+            second = r >= per0;
+            item = second ? jj * per1 + (r - per0) : jj * per0 + r;
+        }
+    }
+    const PgasrTn256Args g = second ? g1 : g0;
+    const int tx = g.N / TN, ty = g.M / TM;
+    const unsigned nitems = (unsigned)(tx * ty) * (unsigned)(g.batch * g.splitk);
+    if (!g0.queue) {
         // plain launch: workgroups are dealt round-robin over the 8 XCDs (observed, speed only), so workgroup b shares an L2
         // with b + 8, b + 16, ..: give every XCD WHOLE K-slabs -- the tiles of a slab read the same k-rows (an A byte is
         // read by N/256 of them, a B byte by M/256), and side by side behind one L2 they fetch them from HBM once
@@ -449,23 +471,67 @@ __global__ __launch_bounds__(THREADS) void gemm_t256_kernel(PgasrTn256Args g) {
     }
     if (item >= nitems) return;
     // items of one K-slab are adjacent: they run at the same time and share the slab's rows in L2 / MALL
-    const int z = (int)(item / (unsigned)(tx * ty)), t2 = (int)(item % (unsigned)(tx * ty));
+    int z = (int)(item / (unsigned)(tx * ty)), t2 = (int)(item % (unsigned)(tx * ty));
+    int bidx = z / g.splitk, sidx = z % g.splitk;
+    int k_beg = sidx * g.kper, k_end = (k_beg + g.kper < g.K) ? k_beg + g.kper : g.K;
+    if (g.tslabs) {
+        // item = (time slab in the order a backward sweep completes them, batch, tile); see pgasr_wslab_edge (common.h)
+        const unsigned per = (unsigned)(tx * ty * g.batch);
+        const int jj = (int)(item / per), rem = (int)(item % per);
+        bidx = rem / (tx * ty); t2 = rem % (tx * ty);
+        const long long off = (long long)(g.A - g.gate_base) + (long long)bidx * g.sA + (long long)(t2 / tx) * TM;
+        const int row_off = (int)(off / g.lda), dir = (off % g.lda) >= g.lda / 2 ? 1 : 0;
+        const int n = g.splitk, T = g.gate_T;
+        const int h_lo = pgasr_wslab_edge(T, n - jj - 1), h_hi = pgasr_wslab_edge(T, n - jj);
+        const long long ra = (long long)(dir ? T - h_hi : h_lo) * g.gate_B - row_off, rb = (long long)(dir ? T - h_lo : h_hi) * g.gate_B - row_off;
+        k_beg = ra < 0 ? 0 : (int)ra; k_end = rb > g.K ? g.K : (int)rb;
+        sidx = jj; z = bidx * g.splitk + sidx;
+        if constexpr (GATED) {
+            if (tid < 64) {
+                const int t_lo = (row_off + k_beg) / g.gate_B, t_hi = (row_off + k_end - 1) / g.gate_B;
+                const int s_last = dir ? t_hi : T - 1 - t_lo;          // the last sweep step that writes one of these rows
+                unsigned need = 1;                                      // publication k covers sweep steps < T - h_(n-k)
+                while ((int)need < n && T - pgasr_wslab_edge(T, n - (int)need) <= s_last) ++need;
+                unsigned spins = 0; long long t0 = 0;
+                while (true) {
+                    asm volatile("" ::: "memory");
+                    unsigned v = need;
+                    if (lane < g.gate_nbg) v = __hip_atomic_load(g.gate + 2 * lane + dir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!__any(v < need)) break;
+                    __builtin_amdgcn_s_sleep(32);
+                    if (((++spins) & 255u) == 0) {
+                        const long long now = wall_clock64();
+                        if (spins == 256u) t0 = now;
+                        else if (now - t0 > 300000000LL) { if (g.gate_err) *g.gate_err = 1; break; }     // 3 s of the 100 MHz clock
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
     const int tbx = t2 % tx, tby = t2 / tx;
-    const int bidx = z / g.splitk, sidx = z % g.splitk;
-    const int k_beg = sidx * g.kper, k_end = (k_beg + g.kper < g.K) ? k_beg + g.kper : g.K;
     const int nk = (k_end - k_beg) / TK;               // >= 1 (pgasr_internal_tn256_ok: no empty slab)
     const int m0 = tby * TM, n0 = tbx * TN;
     // wave w loads k-rows 4 w + j (j = 0..3) of both operands: one 1-KB row per wave instruction
     const float* Ab = g.A + (size_t)bidx * g.sA + (size_t)(k_beg + 4 * w) * g.lda + m0 + 4 * lane;
     const float* Bb = g.B + (size_t)bidx * g.sB + (size_t)(k_beg + 4 * w) * g.ldb + n0 + 4 * lane;
     f32x4_t ra[4], rb[4];
+    // GATED: this item's A rows as a buffer (kper * lda * 4 < 2^31, checked by the launcher): sc1 loads
+    __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + (size_t)bidx * g.sA + (size_t)k_beg * g.lda + m0), 0,
+                                                                   GATED ? (int)((size_t)nk * TK * g.lda * 4) : 0, 0x00020000);
     auto load = [&](int kt) {
         const int kc = kt < nk ? kt : nk - 1;          // past the slab: reload the last step (never converted)
         const float* pa = Ab + (size_t)kc * TK * g.lda;
         const float* pb = Bb + (size_t)kc * TK * g.ldb;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            ra[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(pa + (size_t)j * g.lda));
+            if constexpr (GATED) {
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+                const u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(ars, (unsigned)(((size_t)(kc * TK + 4 * w + j) * g.lda + 4 * lane) * 4), 0, 16);
+                ra[j] = __builtin_bit_cast(f32x4_t, u);
+            } else {
+                ra[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(pa + (size_t)j * g.lda));
+            }
             rb[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(pb + (size_t)j * g.ldb));
         }
     };
@@ -548,7 +614,7 @@ __global__ __launch_bounds__(THREADS) void gemm_t256_kernel(PgasrTn256Args g) {
             for (int r = 0; r < 16; ++r)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(g.alpha * acc[i][j][r]), prs, o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.N * 4), 0, 0);
         }
-    if (!g.queue) return;
+    if (!g0.queue) return;
     __syncthreads();           // every read of this item's last buffer is done before the mailbox / the next item's images are written
   }
 }
@@ -580,31 +646,48 @@ int pgasr_internal_x3c_launch(const PgasrX3cArgs& a, hipStream_t st) {
 }
 
 bool pgasr_internal_tn256_ok(const PgasrTn256Args& a) {
+    if (a.gate && (!a.queue || !a.tslabs || a.gate_nbg <= 0 || a.gate_nbg > 32)) return false;
+    if (a.tslabs) {
+        if (!a.gate_base || a.gate_T <= 0 || a.gate_B <= 0 || (a.gate_B % 32) || a.A < a.gate_base || (a.lda & 1)) return false;
+        if (a.splitk != pgasr_wslab_count(a.gate_T) || (size_t)a.gate_T * a.gate_B * a.lda * 4 >= ((size_t)1 << 31)) return false;
+        // no empty slab: every batch's rows must reach into the first and the last 16 frames
+        const long long first = (long long)((a.A - a.gate_base) / a.lda), last = first + a.K;
+        if (first >= 16LL * a.gate_B || last <= (long long)(a.gate_T - 16) * a.gate_B) return false;
+    }
     // PGASR_TN_TILE=128 (read at every call) keeps gemm.hip's 128 x 128 kernel (A/B measurements)
     const char* e = getenv("PGASR_TN_TILE");
     if (e && e[0] == '1' && e[1] == '2' && e[2] == '8') return false;
     if (!a.A || !a.B || !a.partial || a.M <= 0 || a.N <= 0 || a.K < 32 || a.batch <= 0 || a.splitk <= 0) return false;
-    if ((a.M % t256::TM) || (a.N % t256::TN) || (a.K % 32) || (a.kper % 32) || (a.lda & 3) || (a.ldb & 3)) return false;
+    if ((a.M % t256::TM) || (a.N % t256::TN) || (a.K % 32) || (!a.tslabs && (a.kper % 32)) || (a.lda & 3) || (a.ldb & 3)) return false;
     if ((a.sA & 3) || (a.sB & 3) || (((size_t)a.A) & 15) || (((size_t)a.B) & 15)) return false;
-    if ((long long)(a.splitk - 1) * a.kper >= a.K) return false;        // no empty slab
+    if (!a.tslabs && (long long)(a.splitk - 1) * a.kper >= a.K) return false;        // no empty slab
     if ((size_t)a.M * a.N * 4 >= ((size_t)1 << 32)) return false;
     return true;
 }
 
-int pgasr_internal_tn256_launch(PgasrTn256Args a, int masked_then_unmasked, hipStream_t st) {
+int pgasr_internal_tn256_launch(PgasrTn256Args a, int masked_then_unmasked, hipStream_t st, const PgasrTn256Args* second) {
+    PgasrTn256Args b{};
+    if (second) {
+        if (!a.queue || second->splitk != a.splitk || !pgasr_internal_tn256_ok(*second)) return PGASR_ERR_UNSUPPORTED;
+        b = *second;
+    }
     const size_t lds = (size_t)t256::LDS_BYTES;
-    if (hipFuncSetAttribute((const void*)t256::gemm_t256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)t256::gemm_t256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
     const unsigned nitems = (unsigned)((a.N / t256::TN) * (a.M / t256::TM)) * (unsigned)(a.batch * a.splitk);
     if (!a.queue) {
-        PGASR_LAUNCH_KERNEL(t256::gemm_t256_kernel, dim3(nitems), dim3(t256::THREADS), lds, st, a);
+        PGASR_LAUNCH_KERNEL(t256::gemm_t256_kernel<false>, dim3(nitems), dim3(t256::THREADS), lds, st, a, b);
         PGASR_CHECK_LAUNCH();
         return PGASR_OK;
     }
+    if (a.gate && hipFuncSetAttribute((const void*)t256::gemm_t256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PGASR_ERR_LAUNCH;
     const unsigned* busy = a.xcc_busy;
-    for (int pass = 0; pass < (masked_then_unmasked ? 2 : 1); ++pass) {
+    for (int pass = 0; pass < ((masked_then_unmasked && busy) ? 2 : 1); ++pass) {
         a.xcc_busy = (pass == 0) ? busy : nullptr;
-        PGASR_LAUNCH_KERNEL(t256::gemm_t256_kernel, dim3(256), dim3(t256::THREADS), lds, st, a);
+        b.xcc_busy = a.xcc_busy;
+        if (a.gate) PGASR_LAUNCH_KERNEL(t256::gemm_t256_kernel<true>, dim3(256), dim3(t256::THREADS), lds, st, a, b);
+        else        PGASR_LAUNCH_KERNEL(t256::gemm_t256_kernel<false>, dim3(256), dim3(t256::THREADS), lds, st, a, b);
         PGASR_CHECK_LAUNCH();
     }
     return PGASR_OK;

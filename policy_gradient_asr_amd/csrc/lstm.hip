@@ -52,6 +52,7 @@ constexpr int RING_STEPS_MAX = 32;     // depth of that ring (steps)
 constexpr int FWD_STEP_FLOATS = 16 * 1024;                           // 16 utterances x (256 units x 4 gates)
 constexpr int BWD_STEP_FLOATS = 16 * 1024 + 16 * 256 + 16 * 256;     // + c_t + dout
 constexpr int LSTM_THREADS = 384;     // 4 compute waves + loader wave + storer wave
+constexpr int HELLO_STRIDE = 64;      // words per cluster in the start-up block
 constexpr int STAMP_MAX_T = 4096;
 constexpr long long SPIN_TIMEOUT_TICKS = 300000000LL;  // 3 s of the 100 MHz realtime counter
 
@@ -85,7 +86,8 @@ struct LstmArgs {
     float* dbias_part;       // (backward, optional) [ceil(B/16)][2][H][4]: per 16-utterance group sums over t of dgates
     const u32x4* wpack;      // packed bf16 hi/lo W_hh in MFMA A-operand order (see pack kernel)
     unsigned char* xbuf;     // exchange buffers, pre-filled with the "stale" pattern
-    unsigned* hello;         // [clusters][16] start-up words (XCC id of each member), zeroed per call
+    unsigned* hello;         // [clusters][HELLO_STRIDE] words, zeroed per call: 0..15 start-up words (XCC id of each member), 16 the
+                             // flusher's, 32..47 "stored" (slabs whose dgates stores a member's storer wave has seen acknowledged)
     unsigned* progress;      // [clusters] current step of member 0 (paces the helpers), zeroed per call
     float* ring;             // [clusters][RING_STEPS][step floats]: the rows of the next steps, staged by the helper workgroups
     unsigned* ready;         // [clusters][32]: word i = (step + 1) held by ring slot i (0 = nothing yet), zeroed per call
@@ -95,6 +97,9 @@ struct LstmArgs {
                              // backward: the fed tensor is dout = the input gradient of the layer above, optionally still
                              // WITHOUT the inter-layer dropout mask, which the helpers then apply while they stage its rows
     unsigned drop_thresh, drop_k0, drop_k1, drop_off; float drop_scale; int drop_on;
+    unsigned* slab_done;     // (backward, optional) [clusters]: publications so far -- publication k says that the dgates rows of sweep steps
+                             // < T - pgasr_wslab_edge(T, n - k) are IN MEMORY, readable by agent-scope loads from any XCD while the sweep
+                             // runs (common.h: the time slabs of the weight-gradient products; published by the cluster's flusher workgroup)
     int* err;                // set to 1 when a bounded wait gives up
     unsigned* busy;          // [8] per-XCD count of clusters currently sweeping there (read by queue-mode GEMMs)
     const int* lengths;      // [B]
@@ -231,7 +236,8 @@ struct SpinGuard {
 // reach memory where any XCD sees them.  Placement only selects the faster legal protocol.
 __device__ __forceinline__ bool cluster_same_xcd(const LstmArgs& a, int cl, int g, int tid, int& s_flag, int& s_abort) {
     if (tid < 64) {
-        unsigned* hw = a.hello + (size_t)cl * 16;
+        unsigned* hw = a.hello + (size_t)cl * HELLO_STRIDE;
+        const int members = a.slab_done ? 17 : 16;     // a streamed sweep's flusher workgroup must share the XCD as well
         const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xFu;
         // bits 16..: HW_REG_HW_ID (cu / sh / se of this workgroup) -- diagnostic only (tools/dev/tools_stamps.py)
         const unsigned hwid = __builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4) & 0xFFFFu;
@@ -240,7 +246,7 @@ __device__ __forceinline__ bool cluster_same_xcd(const LstmArgs& a, int cl, int 
         unsigned v = 0x100u | xcc;
         while (true) {
             POLL_FENCE();
-            if (tid < 16) v = __hip_atomic_load(hw + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < members) v = __hip_atomic_load(hw + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!__any(v == 0u)) break;
             if (!sg.keep_waiting()) { LDS_FLAG_SET(s_abort, 1); *a.err = 1; break; }
         }
@@ -253,6 +259,54 @@ __device__ __forceinline__ bool cluster_same_xcd(const LstmArgs& a, int cl, int 
     return LDS_FLAG_GET(s_flag) != 0;
 }
 
+
+// ---- the flusher workgroup of a STREAMED backward sweep (member index G_CLUSTER + N_HELPERS) -------------------
+// A backward sweep can hand its dgates rows to consumers on OTHER XCDs while it runs (the weight-gradient GEMMs of the
+// same layer, gemm_c256.hip's gated TN kernel): the rows leave the storer waves as plain stores that stay dirty in this
+// XCD's L2 (write-through stores cost the sweep 10 %), so somebody has to write them back.  Every storer wave
+// publishes, per time slab of the weight-gradient products (pgasr_wslab_edge, common.h: n shrinking slabs, the sweep steps
+// < T - h_(n-k) make up the first k), that its stores of the slab are acknowledged (stored[g] = slabs so far);
+// ONE wave of this workgroup waits for the sixteen words, executes the agent-scope release (buffer_wbl2 sc1: the dirty
+// lines of this XCD's L2 go to memory -- the L2 is one per XCD, so the write-back covers every member's lines) and only
+// then publishes slab_done[cluster] = k with an agent-scope store.  Nothing of this sits on the sweep's chain.  Placement is
+// verified as everywhere: this workgroup is the 17th start-up word, and a cluster that does NOT share one XCD with it
+// runs the placement-independent protocol -- the storer waves then release their own stores before they publish, and this
+// wave only aggregates.
+__device__ __forceinline__ void flusher_loop(const LstmArgs& a, int cl) {
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    unsigned* hw = a.hello + (size_t)cl * HELLO_STRIDE;
+    const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xFu;
+    if (lane == 0) __hip_atomic_store(hw + 16, 0x100u | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    SpinGuard sg;
+    unsigned v = 0x100u | xcc;
+    while (true) {
+        POLL_FENCE();
+        if (lane < 16) v = __hip_atomic_load(hw + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!__any(v == 0u)) break;
+        __builtin_amdgcn_s_sleep(8);
+        if (!sg.keep_waiting()) { *a.err = 1; return; }
+    }
+    const bool same = !__any((v & 0xFu) != xcc) && a.force_mode == 0;
+    const unsigned* stored = hw + 32;
+    const int nslab = pgasr_wslab_count(a.T);
+    sg.spins = 0;
+    for (int k = 1; k <= nslab; ++k) {
+        while (true) {
+            POLL_FENCE();
+            unsigned sv = (unsigned)k;
+            if (lane < 16) sv = __hip_atomic_load(stored + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!__any(sv < (unsigned)k)) break;
+            // a sweep that gave up publishes nothing more: leave with it (the consumers' waits are bounded too)
+            if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+            if (!sg.keep_waiting()) { *a.err = 1; return; }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        sg.spins = 0;
+        if (same) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // buffer_wbl2 sc1 + s_waitcnt vmcnt(0)
+        if (lane == 0) __hip_atomic_store(a.slab_done + cl, (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // ---- the cluster's helper workgroups (member indices G_CLUSTER .. G_CLUSTER + N_HELPERS - 1) -------------
 // The compute workgroups must never touch DRAM: measured with the loader wave reading the real (HBM-cold) rows
@@ -278,7 +332,7 @@ __device__ __forceinline__ void helper_loop(const LstmArgs& a, int cl, int dir, 
         unsigned v = 0x100u | xcc;
         while (true) {
             POLL_FENCE();
-            if (lane < 16) v = __hip_atomic_load(a.hello + (size_t)cl * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < 16) v = __hip_atomic_load(a.hello + (size_t)cl * HELLO_STRIDE + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!__any(v == 0u)) break;
             __builtin_amdgcn_s_sleep(8);
             if (!sg0.keep_waiting()) { *a.err = 1; return; }
@@ -729,6 +783,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     const int cl = blockIdx.x % a.NCL8, g = blockIdx.x / a.NCL8;
     if (cl >= 2 * a.NBG) return;
     const int dir = cl & 1, bg = cl >> 1;
+    if (g >= G_CLUSTER + a.n_helpers) { flusher_loop(a, cl); return; }      // launched only with slab_done
     if (g >= G_CLUSTER) { helper_loop(a, cl, dir, bg, g - G_CLUSTER, true, nullptr); return; }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = lane >> 4, n = lane & 15;      // MFMA coordinates
@@ -841,12 +896,28 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
             if (LDS_FLAG_GET(s_abort)) break;
         }
     } else if (w == STORER_WAVE) {
+        // streamed sweep: stored[g] = k once the dgates stores of sweep steps < T - h_(n-k) are acknowledged (see
+        // flusher_loop).  The wait sits in FRONT of a step's stores, a whole step after the youngest store it covers was
+        // issued, so it normally finds nothing outstanding.
+        unsigned* stored = a.hello + (size_t)cl * HELLO_STRIDE + 32 + g;
+        const int nslab = a.slab_done ? pgasr_wslab_count(T) : 0;
+        int next_pub = nslab > 1 ? T - pgasr_wslab_edge(T, nslab - 1) : T + 1;
+        unsigned k_pub = 1;
+        auto publish = [&]() {
+            if (same_xcd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // members on several XCDs: each releases its own stores
+            if (lane == 0) __hip_atomic_store(stored, k_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ++k_pub;
+        };
+        int aborted = 0;
         for (int step = 0; step < T; ++step) {
             LDS_BARRIER();
-            const int aborted = LDS_FLAG_GET(s_abort);
+            aborted = LDS_FLAG_GET(s_abort);
+            if (step == next_pub) { publish(); next_pub = (int)k_pub < nslab ? T - pgasr_wslab_edge(T, nslab - (int)k_pub) : T + 1; }
             io_store_results(step);
             if (aborted) break;
         }
+        if (nslab && !aborted) publish();       // the last slab (k_pub == number of slabs here)
     } else {
         auto compute_step = [&](const int step, const bool first) -> int {
             const int t = step_t(step);
@@ -1110,8 +1181,8 @@ WsLayout lstm_ws_layout(int B, bool backward) {
     // forward: sized for three planes (24 KiB per parity); the two-plane kernel uses the first 2 x 16 KiB of a cluster's block
     const size_t slot = backward ? (size_t)16 * 16 * 256 * 4 : (size_t)32 * 16 * 3 * 16;
     l.err = 0;                                   // 256 bytes
-    l.hello = 256;                               // [clusters][16] words; err+hello zeroed every call
-    l.progress = l.hello + pgasr_align_up((size_t)ncl * 16 * sizeof(unsigned), 256);   // one 128-B line per cluster
+    l.hello = 256;                               // [clusters][HELLO_STRIDE] words; err+hello zeroed every call
+    l.progress = l.hello + pgasr_align_up((size_t)ncl * HELLO_STRIDE * sizeof(unsigned), 256);   // one 128-B line per cluster
     l.ready = l.progress + pgasr_align_up((size_t)ncl * 128, 256);                    // [cluster][32 words], zeroed every call
     l.xbuf = l.ready + pgasr_align_up((size_t)ncl * 128, 256);
     l.xbytes = (size_t)ncl * 2 * slot;           // [cluster][parity][slot], filled with 0x00000001 every call
@@ -1178,8 +1249,9 @@ extern "C" size_t pgasr_lstm_workspace_bytes(int T, int B, int backward) {
 static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, const float* dout, float* dbias_part, const void* wpack,
                        const int* lengths, int T, int B, int flags, void* workspace, size_t workspace_bytes, hipStream_t st,
                        const unsigned* fed = nullptr, int fed_need = 0, float drop_p = 0.f, uint64_t drop_seed = 0,
-                       uint32_t drop_offset = 0, float* out_drop = nullptr) {
+                       uint32_t drop_offset = 0, float* out_drop = nullptr, unsigned* slab_done = nullptr) {
     if (!gates || !out || !cbuf || !wpack || !lengths || T <= 0 || B <= 0) return PGASR_ERR_INVALID_ARG;
+    if (slab_done && !backward) return PGASR_ERR_INVALID_ARG;
     if (backward && !dout) return PGASR_ERR_INVALID_ARG;
     const WsLayout l = lstm_ws_layout(B, backward);
     if (!workspace || workspace_bytes < l.total) return PGASR_ERR_WORKSPACE;
@@ -1210,6 +1282,9 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
     // with 2 x 20 workgroups on one XCD): with more than 8 clusters the loaders read HBM themselves, as before.
     a.n_helpers = (2 * l.NBG <= 8 && !(flags & 4)) ? N_HELPERS : 0;      // flags bit 2: no helpers (two processes sharing one GPU)
     a.fed = fed; a.fed_mt = (int)(((size_t)T * B + 255) / 256); a.fed_need = fed_need;
+    a.slab_done = slab_done;
+    // a streamed sweep needs its flusher workgroup next to the cluster and XCDs left over for the consumers
+    if (slab_done && (a.n_helpers == 0 || 2 * l.NBG > 4)) return PGASR_ERR_UNSUPPORTED;
     if (fed) {
         // a fed sweep waits for a GEMM that must find XCDs of its own: helpers on, at most 4 clusters (half the chip)
         if (fed_need <= 0 || a.n_helpers == 0 || 2 * l.NBG > 4) return PGASR_ERR_UNSUPPORTED;
@@ -1225,7 +1300,7 @@ static int lstm_launch(bool backward, float* gates, float* out, float* cbuf, con
         a.drop_scale = 1.f / (1.f - drop_p);
         a.drop_k0 = (uint32_t)(drop_seed & 0xffffffffu); a.drop_k1 = (uint32_t)(drop_seed >> 32); a.drop_off = drop_offset;
     }
-    dim3 grid((G_CLUSTER + a.n_helpers) * l.NCL8);   // + the helper workgroups of each cluster
+    dim3 grid((G_CLUSTER + a.n_helpers + (slab_done ? 1 : 0)) * l.NCL8);   // + the helper workgroups (+ the flusher) of each cluster
     // flags bit 1: three bf16 planes per fp32 operand (the fp32-faithful sweeps); `wpack` must have been packed with planes = 3
     const bool three = (flags & 2) != 0;
     if (backward) {
@@ -1275,6 +1350,24 @@ extern "C" int pgasr_lstm_layer_bwd_fed(float* gates, const float* out, const fl
                        flags, workspace, workspace_bytes, (hipStream_t)stream, fed, fed_need, drop_p, drop_seed, drop_offset);
 }
 
+// Backward sweep that publishes its progress for consumers running BESIDE it (the same layer's weight-gradient products,
+// pgasr_lstm_wgrads_streamed): slab_done[c] (c = 2 * (16-utterance group) + direction; zeroed by the caller before this launch)
+// counts publications; publication k (k = 1 .. n = pgasr_lstm_wgrad_slabs(T)) says that the d(pre-activation) rows of sweep
+// steps < T - h_(n-k) are in memory and readable with agent-scope loads from any XCD.  Sweep step s is frame T-1-s for
+// direction 0 and frame s for direction 1.  fed == NULL: dout is complete (pgasr_lstm_layer_bwd); else as
+// pgasr_lstm_layer_bwd_fed.  Same conditions as the fed sweeps (pgasr_lstm_fed_ok).
+extern "C" int pgasr_lstm_layer_bwd_streamed(float* gates, const float* out, const float* cbuf, const float* dout,
+                                             const void* whh_pack_bwd, const int32_t* lengths, int T, int B, int flags,
+                                             float* dbias_part, const unsigned* fed, int fed_need, float drop_p, uint64_t drop_seed,
+                                             uint32_t drop_offset, unsigned* slab_done,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
+    if (!slab_done) return PGASR_ERR_INVALID_ARG;
+    if (dbias_part && (((size_t)dbias_part) & 15)) return PGASR_ERR_INVALID_ARG;
+    return lstm_launch(true, gates, const_cast<float*>(out), const_cast<float*>(cbuf), dout, dbias_part, whh_pack_bwd, lengths, T, B,
+                       flags, workspace, workspace_bytes, (hipStream_t)stream, fed, fed_need, drop_p, drop_seed, drop_offset,
+                       nullptr, slab_done);
+}
+
 extern "C" int pgasr_lstm_fed_ok(int T, int B, int flags) {
     if (T <= 0 || B <= 0) return 0;
     const WsLayout l = lstm_ws_layout(B, false);
@@ -1319,14 +1412,14 @@ extern "C" int pgasr_lstm_busy_offset(int B, int backward, size_t* offset) {
 namespace {
 // One wave that holds a stream back until a sweep has registered itself (any busy counter != 0) or the
 // time-out passes: gives "sweep first, GEMMs second" dispatch order across two streams.
-__global__ void __launch_bounds__(64) stream_gate_kernel(const unsigned* words, int count, long long timeout_ticks) {
+__global__ void __launch_bounds__(64) stream_gate_kernel(const unsigned* words, int count, unsigned need, long long timeout_ticks) {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();
     for (;;) {
-        unsigned any = 0;
-        for (int i = 0; i < count; ++i) any |= __hip_atomic_load(words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned sum = 0;
+        for (int i = 0; i < count; ++i) sum += __hip_atomic_load(words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         POLL_FENCE();
-        if (any != 0u || wall_clock64() - t0 > timeout_ticks) break;
+        if (sum >= need || wall_clock64() - t0 > timeout_ticks) break;
         __builtin_amdgcn_s_sleep(16);
     }
 }
@@ -1359,7 +1452,17 @@ extern "C" int pgasr_stream_probe(unsigned* words, int timeout_us, void* stream)
 
 extern "C" int pgasr_stream_gate(const unsigned* words, int count, int timeout_us, void* stream) {
     if (!words || count <= 0 || count > 64 || timeout_us < 0 || timeout_us > 100000) return PGASR_ERR_INVALID_ARG;
-    PGASR_LAUNCH_KERNEL(stream_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, count, (long long)timeout_us * 100);
+    PGASR_LAUNCH_KERNEL(stream_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, count, 1u, (long long)timeout_us * 100);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
+
+// The same gate for consumers that WAIT for the sweep (pgasr_lstm_wgrads_streamed): holds `stream` until the busy counters add up to
+// `need` -- every cluster of the sweep has registered, i.e. all of its workgroups are resident -- since workgroups that poll for the
+// sweep's publications must not take CUs the sweep still needs.  Bounded like the other one (timeout_us <= 100000).
+extern "C" int pgasr_stream_gate_sum(const unsigned* words, int count, int need, int timeout_us, void* stream) {
+    if (!words || count <= 0 || count > 64 || need <= 0 || timeout_us < 0 || timeout_us > 100000) return PGASR_ERR_INVALID_ARG;
+    PGASR_LAUNCH_KERNEL(stream_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, count, (unsigned)need, (long long)timeout_us * 100);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }

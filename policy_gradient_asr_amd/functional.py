@@ -11,6 +11,7 @@ HID = hipops.HID
 FEED_AHEAD = os.environ.get("PGASR_FEED_AHEAD", "1") != "0"   # input projections run beside the forward sweeps they feed
 JOIN_FEED = os.environ.get("PGASR_JOIN_FEED", "0") == "1"   # A/B: main stream joins the feed stream after every fed forward sweep
 FEED_BWD = os.environ.get("PGASR_FEED_BWD", "1") != "0"       # .. and the upper layers' input-gradient GEMMs beside the backward sweeps
+STREAM_DW = os.environ.get("PGASR_STREAM_DW", "1") != "0"     # a layer's weight-gradient GEMMs run beside ITS OWN backward sweep (streamed sweep)
 LEAKY_SLOPE = 0.01   # F.leaky_relu default, model.py:50
 
 
@@ -70,6 +71,17 @@ class grad_overlap:
             cls._sides2[k] = streams.side_stream("feed")
         return cls._sides2[k]
 
+    _sides3 = {}
+    _streamed_unjoined = {}   # main stream -> True while the streamed-weight-gradient stream carries work of this step
+
+    @classmethod
+    def third_side_stream(cls):
+        """The stream of the weight-gradient launches that consume a backward sweep WHILE it runs (BLSTMLayerFn.backward)."""
+        k = cls._key()
+        if k not in cls._sides3:
+            cls._sides3[k] = streams.side_stream("streamed_weight_gradients")
+        return cls._sides3[k]
+
     _recent = {}       # the last event recorded on the main stream in the running backward pass (per main stream)
     _feed_unjoined = {}   # main stream -> True while the feed stream carries work of this step that nothing has joined yet
 
@@ -126,6 +138,8 @@ class grad_overlap:
         cls._recent.pop(cls._key(), None)
         if cls._key() in cls._sides:
             torch.cuda.current_stream().wait_stream(cls.side_stream())
+        if cls._streamed_unjoined.pop(cls._key(), False) and cls._key() in cls._sides3:
+            torch.cuda.current_stream().wait_stream(cls._sides3[cls._key()])
         if cls._feed_unjoined.pop(cls._key(), False) and cls._key() in cls._sides2:
             # ONE join of the feed stream per step, and only when the tail of backward has not made it already (the first
             # layer's dW_hh runs on that stream and is joined through the weight-gradient stream): a fed forward sweep is
@@ -289,6 +303,8 @@ class BLSTMLayerFn(torch.autograd.Function):
         ctx.planes_t = prepacked.planes_t
         ctx.fed_bwd = prepacked.fed_bwd       # zeroed counters for this layer's deferred input-gradient GEMM (or None)
         prepacked.fed_bwd = None
+        ctx.slab_words = prepacked.slab       # zeroed publication words for this layer's streamed backward sweep (or None)
+        prepacked.slab = None
         G = 2 * 4 * HID
         gates = torch.empty(T, B, G, dtype=torch.float32, device=x.device)
         out = torch.empty(T, B, 2 * HID, dtype=torch.float32, device=x.device)
@@ -365,6 +381,19 @@ class BLSTMLayerFn(torch.autograd.Function):
             if before is None:
                 before = torch.cuda.Event()
                 before.record()
+        # STREAMED sweep: this layer's own weight-gradient products run beside it on a third stream and consume its dgates
+        # rows slab by slab (the sweep publishes, pgasr_lstm_layer_bwd_streamed) -- they used to wait for the sweep's end and
+        # run beside the NEXT layer's sweep, which left the first layer's in the tail of the step
+        targets = [p.grad for p in ctx.param_refs]
+        stream_own = (grad_overlap.enabled and STREAM_DW and all(t is not None and t.is_contiguous() for t in targets)
+                      and hipops.lstm_wgrads_ok(T, B, I) and hipops.lstm_fed_ok(T, B)
+                      and hipops.streams_concurrent(grad_overlap.third_side_stream()))
+        slab = None
+        if stream_own:
+            slab = ctx.slab_words if (ctx.slab_words is not None and ctx.slab_words.numel() >= 64) else None
+            ctx.slab_words = None             # single use
+            if slab is None:
+                slab = torch.zeros(64, dtype=torch.int32, device=dev)
         if rec is not None:
             # dout does not exist yet: the layer above left its input-gradient GEMM (and the dropout between the layers)
             # to us.  Its first tile groups are computed here, in front of the sweep; then the sweep goes, and the rest of
@@ -372,10 +401,10 @@ class BLSTMLayerFn(torch.autograd.Function):
             if grad_overlap.enabled and rec["head"]():
                 before = torch.cuda.Event()       # the side stream's part must come behind the head (one queue)
                 before.record()
-            _, dbias_part = hipops.lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=True,
-                                                  fed=rec["done"], fed_need=rec["need"], drop=rec["drop"])
+            sweep_ws, dbias_part = hipops.lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=True,
+                                                         fed=rec["done"], fed_need=rec["need"], drop=rec["drop"], slab=slab)
         else:
-            _, dbias_part = hipops.lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=True)   # gates := dgates
+            sweep_ws, dbias_part = hipops.lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=True, slab=slab)   # gates := dgates
         dg = gates
         if grad_overlap.enabled:
             # the layer above left its weight-gradient GEMMs for now: they run beside THIS sweep, whose clusters
@@ -442,6 +471,22 @@ class BLSTMLayerFn(torch.autograd.Function):
             """hh_stream: run the dW_hh product on that stream, beside dW_ih (used where no sweep follows: the tail of
             the step is then two GEMM chains wide instead of one long one)."""
             cur = torch.cuda.current_stream()
+            if hipops.lstm_wgrads_ok(T, B, I):
+                # both products in one launch, summed over the time slabs that the streamed order uses: the same bits
+                dwih = torch.empty(G, I, dtype=torch.float32, device=dev)
+                dwhh = torch.empty(2, 4 * HID, HID, dtype=torch.float32, device=dev)
+                hipops.lstm_wgrads(dg, x, out, T, B, I, dwih, dwhh, busy_ptr=hipops.GEMM_XCC_BUSY_PTR)
+                dbias = torch.empty(G, dtype=torch.float32, device=dev)
+                hipops.colsum(dbias_part, dbias_part.shape[0], G, G, dbias)
+                if accumulate_into is not None:
+                    hipops.lstm_unpack_grads(dwih, dbias, dwhh, I, accumulate_into, accumulate=True)
+                    return None
+                gl_ = [torch.empty(4 * HID, I, device=dev), torch.empty(4 * HID, HID, device=dev),
+                       torch.empty(4 * HID, device=dev), torch.empty(4 * HID, device=dev),
+                       torch.empty(4 * HID, I, device=dev), torch.empty(4 * HID, HID, device=dev),
+                       torch.empty(4 * HID, device=dev), torch.empty(4 * HID, device=dev)]
+                hipops.lstm_unpack_grads(dwih, dbias, dwhh, I, gl_)
+                return gl_
 
             def hh():
                 dwhh_ = torch.zeros(2, 4 * HID, HID, dtype=torch.float32, device=dev)
@@ -480,7 +525,32 @@ class BLSTMLayerFn(torch.autograd.Function):
             hipops.lstm_unpack_grads(dwih, dbias, dwhh, I, gl)
             return gl
 
-        targets = [p.grad for p in ctx.param_refs]
+        if stream_own:
+            s3 = grad_overlap.third_side_stream()
+            fed_done = None
+            if rec is not None:
+                # the GEMM that FEEDS this sweep goes first: workgroups that wait for the sweep must not hold the CUs its
+                # producer needs (the sweep would wait for rows, the products for the sweep: a circle until the time-outs)
+                fed_done = torch.cuda.Event()
+                with torch.cuda.stream(grad_overlap.side_stream()):
+                    fed_done.record()
+            with torch.cuda.stream(s3):
+                s3.wait_event(before)            # the main stream just before the sweep; then ALL of the sweep's clusters must have registered
+                if fed_done is not None:
+                    s3.wait_event(fed_done)
+                hipops.stream_gate(busy, need=2 * ((B + 15) // 16), timeout_us=5000)
+                dwih = torch.empty(G, I, dtype=torch.float32, device=dev)
+                dwhh = torch.empty(2, 4 * HID, HID, dtype=torch.float32, device=dev)
+                hipops.lstm_wgrads(dg, x, out, T, B, I, dwih, dwhh, busy_ptr=busy if grad_overlap.confine else 0,
+                                   slab=slab, err_ws=sweep_ws)
+                s3.wait_event(swept)             # the bias partial sums are written at the sweep's very end
+                dbias = torch.empty(G, dtype=torch.float32, device=dev)
+                hipops.colsum(dbias_part, dbias_part.shape[0], G, G, dbias)
+                hipops.lstm_unpack_grads(dwih, dbias, dwhh, I, targets, accumulate=True)
+            for t_ in (dg, x, out, dbias_part, slab):
+                streams.hold(t_, s3)
+            grad_overlap._streamed_unjoined[grad_overlap._key()] = True
+            return (dx, None, None, None, None, None) + (None,) * 8
         if grad_overlap.enabled and all(t is not None and t.is_contiguous() for t in targets):
             side = grad_overlap.side_stream()
             tail = not ctx.sweep_follows
@@ -504,7 +574,7 @@ class BLSTMLayerFn(torch.autograd.Function):
 
 class PackedBLSTM:
     """What a sweep needs of one layer's parameters, in kernel layouts (made once per step)."""
-    __slots__ = ("wih_perm", "bias_perm", "pack_f", "pack_b", "planes", "planes_t", "ready", "fed_fwd", "fed_bwd")
+    __slots__ = ("wih_perm", "bias_perm", "pack_f", "pack_b", "planes", "planes_t", "ready", "fed_fwd", "fed_bwd", "slab")
 
 
 def prepack_blstm(params, in_dim):
@@ -518,7 +588,7 @@ def prepack_blstm(params, in_dim):
     pk.planes = hipops.split_planes(pk.wih_perm) if ok else None                      # (G, in): forward projection
     pk.planes_t = hipops.split_planes(pk.wih_perm, transpose=True) if ok else None    # (in, G): input gradient
     pk.ready = None
-    pk.fed_fwd = pk.fed_bwd = None      # pre-zeroed tile counters for the feed-ahead GEMMs of this step (prepack_blstm_layers)
+    pk.fed_fwd = pk.fed_bwd = pk.slab = None      # pre-zeroed tile counters / publication words of this step (prepack_blstm_layers)
     return pk
 
 
@@ -533,13 +603,13 @@ def prepack_blstm_layers(layer_params, in_dims, rows=0):
     with torch.cuda.stream(side):
         nl = len(in_dims)
         words = 2 * ((rows + 255) // 256)
-        counters = torch.zeros(2 * nl, max(words, 1), dtype=torch.int32, device=layer_params[0][0].device) if rows > 0 else None
+        counters = torch.zeros(3 * nl, max(words, 64), dtype=torch.int32, device=layer_params[0][0].device) if rows > 0 else None
         if counters is not None:
             streams.hold(counters, main)
         for li, (params, in_dim) in enumerate(zip(layer_params, in_dims)):
             pk = prepack_blstm(params, in_dim)
             if counters is not None:
-                pk.fed_fwd, pk.fed_bwd = counters[2 * li], counters[2 * li + 1]
+                pk.fed_fwd, pk.fed_bwd, pk.slab = counters[2 * li], counters[2 * li + 1], counters[2 * nl + li]
             for t in (pk.wih_perm, pk.bias_perm, pk.pack_f, pk.pack_b) + (pk.planes or ()) + (pk.planes_t or ()):
                 streams.hold(t, main)
             out.append(pk)

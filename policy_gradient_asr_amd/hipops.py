@@ -547,16 +547,26 @@ def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done, order=0, ph
     return ws if phase == 1 else C
 
 
-def lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=False, fed=None, fed_need=0, drop=None):
+def lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=False, fed=None, fed_need=0, drop=None, slab=None):
     """gates := d(pre-activation gates).  want_dbias: also returns the (ceil(B/16), 2*4H) per-group bias-gradient
     partial sums the sweep accumulates on the way (sum its rows).
     fed: counters of a ``gemm_x3w_feed(order=1)`` launched AFTER this call that fills ``dout`` while the sweep runs;
-    drop = (p, seed, offset): dout arrives without that dropout mask, the sweep's helpers apply it."""
+    drop = (p, seed, offset): dout arrives without that dropout mask, the sweep's helpers apply it.
+    slab: STREAMED sweep -- int32 tensor of 2 * ceil(B/16) words, zeroed by the caller, in which the sweep counts the time
+    slabs (``lstm_wgrad_slabs(T)``) whose dgates rows consumers on other XCDs may read (``lstm_wgrads(slab=...)``)."""
     lib = _lib.load()
     ws = _lstm_ws(T, B, True, gates.device)
     part = torch.empty((B + 15) // 16, 2 * 4 * HID, dtype=torch.float32, device=gates.device) if want_dbias else None
     with _timed("lstm_bwd_kernel"):
-        if fed is None:
+        if slab is not None:
+            words = slab
+            if words.dtype != torch.int32 or not words.is_cuda or words.numel() < 2 * ((B + 15) // 16):
+                raise _lib.PgasrError("lstm_layer_bwd: slab_done must be an int32 GPU tensor of 2 * ceil(B/16) words")
+            p, seed, offset = drop if drop is not None else (0.0, 0, 0)
+            st = lib.pgasr_lstm_layer_bwd_streamed(_p(gates), _p(out), _p(cbuf), _p(dout), _p(pack_b), _p(lengths), T, B, _lstm_flags(pack_b),
+                                                   _p(part), _p(fed), int(fed_need), float(p), int(seed), int(offset),
+                                                   _p(words), _p(ws), ws.numel(), _stream())
+        elif fed is None:
             st = lib.pgasr_lstm_layer_bwd(_p(gates), _p(out), _p(cbuf), _p(dout), _p(pack_b), _p(lengths), T, B, _lstm_flags(pack_b),
                                           _p(part), _p(ws), ws.numel(), _stream())
         else:
@@ -568,6 +578,41 @@ def lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=Fal
                                               _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_lstm_layer_bwd")
     return (ws, part) if want_dbias else ws
+
+
+def lstm_wgrad_slabs(T):
+    """Frame boundaries 0 = h_0 < .. < h_n = T of the time slabs the weight-gradient products are summed over."""
+    import ctypes
+    lib = _lib.load()
+    edges = (ctypes.c_int * 64)()
+    n = lib.pgasr_lstm_wgrad_slabs(int(T), ctypes.addressof(edges), 64)
+    return [int(edges[i]) for i in range(n + 1)]
+
+
+def lstm_wgrads_ok(T, B, in_dim):
+    """Shapes ``lstm_wgrads`` takes (the 256 x 256 TN kernel: both products in one launch)."""
+    return GEMM_PRECISION == 1 and T >= 2 and in_dim % 256 == 0 and B % 32 == 0 and T * B * 2048 * 4 < 2 ** 31
+
+
+def lstm_wgrads(dgates, x, out, T, B, in_dim, dwih, dwhh, busy_ptr=0, slab=None, err_ws=None):
+    """dwih (2*4H, in_dim) = dgates^T x and dwhh (2, 4H, H) = dgates[d]^T h_prev(d) in one launch, summed over the time slabs
+    of ``lstm_wgrad_slabs(T)``.  slab: the slab_done words of the STREAMED sweep that is still writing ``dgates`` on another
+    stream; err_ws: that sweep's workspace (its error word is set if a wait gives up)."""
+    lib = _lib.load()
+    for t_, nm in ((dgates, "dgates"), (x, "x"), (out, "out"), (dwih, "dwih"), (dwhh, "dwhh")):
+        _req(t_, torch.float32, nm)
+    nbytes = lib.pgasr_lstm_wgrads_workspace_bytes(T, in_dim)
+    ws = _workspace(nbytes, dgates.device, "gemm")
+    err_ptr = 0
+    if err_ws is not None:
+        import ctypes
+        off = ctypes.c_size_t(0)
+        _lib.check(lib.pgasr_lstm_error_offset(B, 1, ctypes.byref(off)), "pgasr_lstm_error_offset")
+        err_ptr = err_ws.data_ptr() + off.value
+    with _timed("gemm_f32"):
+        st = lib.pgasr_lstm_wgrads_streamed(_p(dgates), _p(x), _p(out), T, B, in_dim, _p(dwih), _p(dwhh), int(busy_ptr),
+                                            _p(slab), err_ptr, _p(ws), ws.numel(), _stream())
+    _lib.check(st, "pgasr_lstm_wgrads_streamed")
 
 
 def lstm_check_error(ws, B, backward):
@@ -741,7 +786,11 @@ def streams_concurrent(other):
     return _concurrent[key]
 
 
-def stream_gate(words_ptr, count=8, timeout_us=60):
-    """Hold the current stream until a sweep has registered in the busy counters at ``words_ptr``."""
+def stream_gate(words_ptr, count=8, timeout_us=60, need=0):
+    """Hold the current stream until a sweep has registered in the busy counters at ``words_ptr``; need > 0: until ``need``
+    clusters have (consumers that wait for the sweep's publications: all of its workgroups must be resident first)."""
     lib = _lib.load()
-    _lib.check(lib.pgasr_stream_gate(words_ptr, count, timeout_us, _stream()), "pgasr_stream_gate")
+    if need > 0:
+        _lib.check(lib.pgasr_stream_gate_sum(words_ptr, count, int(need), timeout_us, _stream()), "pgasr_stream_gate_sum")
+    else:
+        _lib.check(lib.pgasr_stream_gate(words_ptr, count, timeout_us, _stream()), "pgasr_stream_gate")

@@ -290,8 +290,11 @@ class PolicyGradientTrainer(DataParallelStep):
         after the sweep (``swept``): a collective kernel never runs beside a sweep's latency chain."""
         from .functional import grad_overlap
         side = grad_overlap.side_stream()
+        s3 = grad_overlap._sides3.get(grad_overlap._key()) if grad_overlap._streamed_unjoined.get(grad_overlap._key()) else None
         with torch.cuda.stream(side):
             side.wait_event(swept)
+            if s3 is not None:
+                side.wait_stream(s3)      # streamed sweeps: the upper layers' weight gradients were issued THERE (the first layer's are not yet)
             self.reduce_upper(self.upper_split)
 
     def backward(self, loss):

@@ -322,6 +322,76 @@ def test_blstm_fed_by_concurrent_projection_matches_sequential(T, B, lens):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("T,B,lens,flags", [
+    (200, 32, [200] * 32, 0),                               # the headline geometry
+    (1000, 32, [1000] * 20 + list(range(999, 987, -1)), 0),   # the headline length: 11 slabs
+    (130, 32, [130] * 9 + list(range(129, 106, -1)), 0),    # very ragged
+    (20, 32, [20] * 32, 0),                                 # a single slab
+    (200, 32, [200] * 32, 1),                               # write-through protocol: the storer waves release their own stores
+])
+def test_streamed_backward_sweep_feeds_its_own_weight_gradients(T, B, lens, flags):
+    """pgasr_lstm_layer_bwd_streamed + pgasr_lstm_wgrads_streamed: the weight-gradient products of a layer run BESIDE the backward
+    sweep that is still writing their dgates operand (flusher workgroup: L2 write-back per time slab, slab_done words; gated TN
+    kernel: waits per slab, agent-scope loads).  Bit-identical to the sequential order (sweep, then the same launch un-gated), and
+    equal to the fp64 product of the same dgates to bf16x3 accuracy."""
+    from policy_gradient_asr_amd import functional as Fh, hipops, streams
+    dev = torch.device(DEV)
+    side = streams.side_stream("test_streamed")
+    if not hipops.streams_concurrent(side):
+        pytest.skip("kernels of different streams are serialised here (profiler / launch-blocking)")
+    assert hipops.lstm_wgrads_ok(T, B, 512) and not hipops.lstm_wgrads_ok(T, 20, 512)
+    edges = hipops.lstm_wgrad_slabs(T)
+    assert edges[0] == 0 and edges[-1] == T and all(a < b for a, b in zip(edges, edges[1:]))
+    if T == 1000:
+        assert edges == [0, 16, 40, 72, 120, 184, 272, 392, 560, 728, 896, 1000]
+    lstm, x, dy, lengths = _lstm_case(T, B, lens, seed=11 + T)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0",
+             "weight_ih_l0_reverse", "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+    params = [getattr(lstm, n).detach().to(dev).contiguous() for n in names]
+    wih, bias, pf, pb = hipops.lstm_pack(params, 512)
+    xd, dyd, ln = x.to(dev), dy.to(dev), lengths.to(torch.int32).to(dev)
+    G, H = 2048, 256
+    gates0 = torch.empty(T, B, G, device=dev)
+    hipops.gemm(xd, wih, gates0, M=T * B, N=G, K=512, transB=True, bias=bias)
+    out = torch.empty(T, B, 2 * H, device=dev); cbuf = torch.empty(T, B, 2 * H, device=dev)
+    hipops.lstm_layer_fwd(gates0, out, cbuf, pf, ln, T, B)           # gates0 := saved activations
+    prev_flags = hipops.LSTM_FLAGS
+    hipops.LSTM_FLAGS = flags
+    try:
+        # sequential order
+        dg_ref = gates0.clone()
+        hipops.lstm_layer_bwd(dg_ref, out, cbuf, dyd, pb, ln, T, B)
+        dwih_ref = torch.empty(G, 512, device=dev); dwhh_ref = torch.empty(2, 4 * H, H, device=dev)
+        hipops.lstm_wgrads(dg_ref, xd, out, T, B, 512, dwih_ref, dwhh_ref)
+        d64, x64, o64 = dg_ref.double().cpu(), xd.double().cpu(), out.double().cpu()
+        want_ih = d64.reshape(T * B, G).t() @ x64.reshape(T * B, 512)
+        assert rel_err(dwih_ref.cpu(), want_ih) < 2e-5
+        want_hh0 = d64[1:, :, :4 * H].reshape(-1, 4 * H).t() @ o64[:-1, :, :H].reshape(-1, H)
+        want_hh1 = d64[:-1, :, 4 * H:].reshape(-1, 4 * H).t() @ o64[1:, :, H:].reshape(-1, H)
+        assert rel_err(dwhh_ref[0].cpu(), want_hh0) < 2e-5 and rel_err(dwhh_ref[1].cpu(), want_hh1) < 2e-5
+        for rep in range(2):
+            dg = gates0.clone()
+            words = torch.zeros(64, dtype=torch.int32, device=dev)
+            dwih = torch.full((G, 512), float("nan"), device=dev); dwhh = torch.full((2, 4 * H, H), float("nan"), device=dev)
+            torch.cuda.synchronize()
+            before = torch.cuda.Event(); before.record()
+            ws = hipops.lstm_layer_bwd(dg, out, cbuf, dyd, pb, ln, T, B, slab=words)
+            busy = hipops.lstm_busy_ptr(T, B, True, dev)
+            with torch.cuda.stream(side):
+                side.wait_event(before)
+                hipops.stream_gate(busy, need=2 * ((B + 15) // 16), timeout_us=5000)
+                hipops.lstm_wgrads(dg, xd, out, T, B, 512, dwih, dwhh, busy_ptr=busy, slab=words, err_ws=ws)
+            torch.cuda.synchronize()
+            hipops.lstm_check_error(ws, B, True)
+            nc = 2 * ((B + 15) // 16)
+            assert words[:nc].tolist() == [len(edges) - 1] * nc
+            assert torch.equal(dg, dg_ref)
+            assert torch.equal(dwih, dwih_ref), float((dwih - dwih_ref).abs().max())
+            assert torch.equal(dwhh, dwhh_ref), float((dwhh - dwhh_ref).abs().max())
+    finally:
+        hipops.LSTM_FLAGS = prev_flags
+
+
 def test_sweep_error_word_is_sticky_and_checked():
     """A sweep that gives up on a bounded wait sets the first word of its workspace; no later launch clears it and
     hipops.lstm_assert_no_timeouts() (called by bench.py and model.train) raises.  The flag is forged here."""
