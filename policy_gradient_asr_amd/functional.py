@@ -527,10 +527,12 @@ class BLSTMLayerFn(torch.autograd.Function):
 
         if stream_own:
             s3 = grad_overlap.third_side_stream()
+            # Everything queued on the side stream for THIS sweep's time goes first -- above all the GEMM that feeds the sweep:
+            # workgroups that wait for the sweep must not hold the CUs its producer needs (the sweep would wait for rows, the
+            # products for the sweep: a circle until the time-outs); and the head's weight gradients beside the top layer's
+            # sweep, which otherwise sit behind the waiting workgroups until the sweep ends and then delay the next feed
             fed_done = None
-            if rec is not None:
-                # the GEMM that FEEDS this sweep goes first: workgroups that wait for the sweep must not hold the CUs its
-                # producer needs (the sweep would wait for rows, the products for the sweep: a circle until the time-outs)
+            if grad_overlap._key() in grad_overlap._sides:
                 fed_done = torch.cuda.Event()
                 with torch.cuda.stream(grad_overlap.side_stream()):
                     fed_done.record()

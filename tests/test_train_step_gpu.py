@@ -429,11 +429,11 @@ def test_weight_grad_overlap_gives_identical_gradients():
     assert torch.equal(grads[0], grads[1])
 
 
-def _trainer_and_batch(seed=3, train=False):
+def _trainer_and_batch(seed=3, train=False, B=20, T=60):
     from policy_gradient_asr_amd.model import Seq2Seq, weights
     from policy_gradient_asr_amd.train_step import PolicyGradientTrainer
-    B, F, T, V, L = 20, 80, 60, 29, 6
-    x, targets, fmask, tmask = _make(B, F, T, V, L, [60] * 10 + [41] * 10, [6] * 20, seed)
+    F, V, L = 80, 29, 6
+    x, targets, fmask, tmask = _make(B, F, T, V, L, [T] * (B // 2) + [T - 19] * (B - B // 2), [6] * B, seed)
     torch.manual_seed(0)
     m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(DEV)
     m = m.train() if train else m.eval()
@@ -441,11 +441,12 @@ def _trainer_and_batch(seed=3, train=False):
     return tr, tuple(t.to(DEV) for t in (x, targets, fmask, tmask))
 
 
-def test_upper_bucket_is_complete_where_its_allreduce_is_issued():
+@pytest.mark.parametrize("B,T", [(20, 60), (32, 200)])     # B = 32: streamed sweeps, the upper layers' weight gradients come from a third stream
+def test_upper_bucket_is_complete_where_its_allreduce_is_issued(B, T):
     """N>1 ordering (train_step.PolicyGradientTrainer._upper_grads_issued): at the point of the side stream where the
     first bucket's all-reduce is enqueued, the gradients of the head and of BLSTM layers 1 and 2 are final.  The
     collective is replaced by a snapshot taken in stream order at exactly that point."""
-    tr, batch = _trainer_and_batch(train=True)
+    tr, batch = _trainer_and_batch(train=True, B=B, T=T)
     snaps = []
     tr.collective = True
     tr.reduce_upper = lambda split: snaps.append((split, tr.gflat[split:].clone()))
@@ -514,6 +515,34 @@ def test_feed_ahead_gemms_give_identical_train_steps():
         Fh.FEED_AHEAD = prev
     for a, b in zip(*res):
         assert torch.equal(a, b)
+    assert float(res[0][0].abs().sum()) > 0
+
+
+def test_streamed_weight_gradients_give_identical_train_steps():
+    """functional.STREAM_DW: every BLSTM layer's weight-gradient products run beside that layer's OWN backward sweep and consume
+    its dgates slab by slab (pgasr_lstm_layer_bwd_streamed / pgasr_lstm_wgrads_streamed).  Gradients and parameters equal, bit for
+    bit, those of the order in which the products wait for the sweep's end, with and without the overlap machinery."""
+    from policy_gradient_asr_amd import functional as Fh, hipops
+    assert hipops.lstm_wgrads_ok(200, 32, 512)
+    prev = Fh.STREAM_DW
+    res = []
+    try:
+        for stream_dw, overlap in ((False, True), (True, True), (True, True), (False, False)):
+            Fh.STREAM_DW = stream_dw
+            tr, batch = _trainer_and_batch(train=True, B=32, T=200)
+            tr.overlap_weight_grads = overlap
+            tr.step(*batch)
+            torch.cuda.synchronize()
+            g1 = tr.gflat.clone()
+            tr.step(*batch)
+            torch.cuda.synchronize()
+            hipops.lstm_assert_no_timeouts()
+            res.append((g1, tr.gflat.clone(), tr.flat.clone()))
+    finally:
+        Fh.STREAM_DW = prev
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
     assert float(res[0][0].abs().sum()) > 0
 
 
