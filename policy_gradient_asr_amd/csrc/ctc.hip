@@ -9,6 +9,15 @@
 //   ctc_grad_kernel    : one wave per (t,b): posterior occupancy per label from alpha+beta,
 //       grad = scale_b * (softmax - occupancy) [+ REINFORCE term], fully parallel over T*B.
 //
+// Measured and NOT kept (round 3): a barrier-free lattice for S <= 256 -- one state per lane, neighbours by DPP wave_shr:1 /
+// wave_shl:1, the four compute waves as a pipeline that hands only its two edge states per frame through an LDS ring with
+// frame counters (prefetched a frame ahead), the storer following the counters four frames at a time.  Bit-identical, and
+// no faster: 268-298 us against 272.  Switching its parts off one by one (diagnostic flags) showed why: without the
+// neighbour exchange 278 us, without the storer 280, with the emissions prefetched 16 frames ahead 268, with cached
+// emissions 283 -- and with ALL of these AND lse3 removed still 239 us, 0.24 us = ~570 cycles per frame for ~60 dependent
+// instructions of one wave per SIMD.  The frame is bound by the dependent-issue latency of a single wave's instruction
+// chain, not by the barrier, the LDS round trip, the emission loads or the stores; more waves do not shorten a chain.
+//
 // Numerics: alpha/beta are kept in fp64 (adds/max are native fp64 VALU ops) while exp/log
 // run in fp32 on the *differences* to the row maximum, which are O(1..50): absolute error
 // per step ~1e-7 instead of the ~2e-4 ulp an fp32 log-space value of magnitude 3000 has at
@@ -281,195 +290,6 @@ __device__ __forceinline__ void ctc_lattice_body(
     }
 }
 
-// ---- pipelined lattice for S <= 256 (round 3) ----------------------------------------------------------------------
-// The frame recursion above costs ~650 cycles per frame, of which the arithmetic is ~250: the rest is the LDS round trip of the three
-// neighbour reads and the workgroup barrier.  But the dependency between states is one-sided -- alpha_t(s) needs states s, s-1, s-2 of
-// frame t-1, beta the mirror image -- so with one state per lane a wave gets its neighbours by DPP (wave_shr:1 / wave_shl:1, two
-// moves per fp64 value) and needs from OUTSIDE only the two edge states of ONE neighbouring wave.  The four compute waves therefore run
-// as a pipeline without any barrier: wave w publishes each finished frame in an LDS ring (its 64 states, then a frame counter -- LDS
-// requests of a wave are served in order, so whoever reads the counter first and the data second sees complete data), and reads the
-// edge pair of the wave it depends on, one frame ahead of its use.  A wave that finds the pair not there yet re-reads it, which costs
-// it one LDS round trip and makes it trail a little further; once it trails its producer by a frame the prefetched pair is always
-// valid and nothing on the chain waits for LDS.  The storer wave follows the four counters, four frames at a time (same row
-// format and reference refresh as above), and publishes how far it has got; a compute wave re-uses a ring slot only behind that.
-constexpr int PIPE_R = 16;       // ring depth in frames
-#ifndef PGASR_CTC_PIPE_LP
-#define PGASR_CTC_PIPE_LP 16
-#endif
-constexpr int PIPE_LP = PGASR_CTC_PIPE_LP;      // emission prefetch distance in frames (even)
-template <int CTRL> __device__ __forceinline__ double dpp_f64(double old_, double src) {
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old_), __double2loint(src), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old_), __double2hiint(src), CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-#define PIPE_FLAG_GET(var) __hip_atomic_load(&(var), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define PIPE_FLAG_SET(var, val) __hip_atomic_store(&(var), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-
-template <int ROLE>
-__device__ __forceinline__ void ctc_lattice_pipe_body(
-    const float* __restrict__ lp, const int32_t* __restrict__ targets,
-    const int32_t* __restrict__ in_len, const int32_t* __restrict__ tg_len,
-    int T, int B, int V, int Lmax, int blank, CtcWs ws, float* __restrict__ nll_out, int diag) {
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    int Tb = in_len[b]; Tb = Tb < 0 ? 0 : (Tb > T ? T : Tb);
-    int Lb = tg_len[b]; Lb = Lb < 0 ? 0 : (Lb > Lmax ? Lmax : Lb);
-    const int S = 2 * Lb + 1;
-    const int32_t* tgt = targets + (size_t)b * Lmax;
-    __shared__ __attribute__((aligned(16))) double ring[PIPE_R][CTC_THREADS];
-    __shared__ __attribute__((aligned(16))) int tag[4];      // frames finished by compute wave w
-    __shared__ int consumed;                                  // frames the storer has read out of the ring
-    if (tid < 4) tag[tid] = 0;
-    if (tid == 4) consumed = 0;
-    if (Tb == 0) {
-        if (ROLE == 0 && tid == 0) {
-            const double v = (Lb == 0) ? 0.0 : INFINITY;
-            ws.nll64[b] = v; nll_out[b] = (float)v;
-        }
-        return;
-    }
-    __syncthreads();
-    const int t0 = (ROLE == 0) ? 0 : Tb - 1;
-    const int dt = (ROLE == 0) ? 1 : -1;
-    float* out = (ROLE == 0 ? ws.alpha : ws.beta) + (size_t)b * T * ws.SP;
-    double* outmax = (ROLE == 0 ? ws.amax : ws.bmax) + (size_t)b * T;
-
-    if (w == 4) {
-        // ---- storer: four frames per round
-        const int ng = (S + 63) >> 6;           // 64-state groups that hold states (wave-uniform)
-        if (diag & 4) { if (lane == 0) PIPE_FLAG_SET(consumed, 1 << 30); }      // diag bit 2: no storer at all
-        else
-        for (int f = 0; f < Tb; f += 4) {
-            const int n = (Tb - f < 4) ? Tb - f : 4;
-            // a slot is handed back only when every wave has finished the frame AFTER it, i.e. has read the edge pair it
-            // needed from it (the producer of that pair may be up to R - 1 frames ahead and would overwrite it)
-            const int need = (f + n + 1 < Tb) ? f + n + 1 : Tb;
-            while (true) {
-                asm volatile("" ::: "memory");
-                const int t0_ = PIPE_FLAG_GET(tag[0]), t1_ = PIPE_FLAG_GET(tag[1]), t2_ = PIPE_FLAG_GET(tag[2]), t3_ = PIPE_FLAG_GET(tag[3]);
-                const int lo01 = t0_ < t1_ ? t0_ : t1_, lo23 = t2_ < t3_ ? t2_ : t3_;
-                if ((lo01 < lo23 ? lo01 : lo23) >= need) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            asm volatile("" ::: "memory");
-            double v[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int slot = (f + (r < n ? r : 0)) & (PIPE_R - 1);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[r][i] = PIPE_FLAG_GET(ring[slot][lane + 64 * i]);     // relaxed LDS loads (ds_read_b64), never cached in registers
-            }
-            // the reference of the four rows: the maximum of the first (see store_row above)
-            double ml = fmax(fmax(v[0][0], v[0][1]), fmax(v[0][2], v[0][3]));
-            const double mw = (double)wave_max_f32_all((float)ml);
-            const double m = (mw == -INFINITY) ? 0.0 : mw;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (r < n) {
-                    const int t_row = t0 + (f + r) * dt;
-                    float* o = out + (size_t)t_row * ws.SP + lane;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (i < ng) o[64 * i] = (float)(v[r][i] - m);
-                    if (lane == 0) outmax[t_row] = m;
-                }
-            }
-            asm volatile("" ::: "memory");
-            if (lane == 0) PIPE_FLAG_SET(consumed, f + n);
-        }
-    } else {
-        // ---- compute wave w: states 64 w .. 64 w + 63, one per lane
-        const int s = tid;
-        int lab = blank; bool skip = false;
-        if (s < S && (s & 1)) lab = tgt[s >> 1];
-        if (ROLE == 0) { if (s < S && (s & 1) && s >= 3) skip = (tgt[s >> 1] != tgt[(s >> 1) - 1]); }
-        else           { if (s + 2 < S && (s & 1)) skip = (tgt[(s >> 1) + 1] != tgt[s >> 1]); }
-        if (lab < 0 || lab >= V) lab = blank;
-        const bool has_nb = ((ROLE == 0) ? (w > 0) : (w < 3)) && !(diag & 1);     // diag (PGASR_CTC_DIAG, results invalid): bit 0 no neighbour, bit 1 no lse3
-        const int nb = (ROLE == 0) ? w - 1 : w + 1;
-        const int eidx = (ROLE == 0) ? 64 * w - 2 : 64 * (w + 1);      // the pair [eidx], [eidx + 1] (16-byte aligned)
-        auto lp_at = [&](int k) {                                        // emission of frame index k (clamped: loads never leave the utterance)
-            const int kc = (diag & 8) ? 0 : (k < Tb ? k : Tb - 1);      // diag bit 3: every frame re-reads frame 0's emission (a cache hit)
-            return lp[((size_t)(t0 + kc * dt) * B + b) * V + lab];
-        };
-        double a = -INFINITY;
-        {
-            const float l0 = lp_at(0);
-            if (ROLE == 0) { if (s <= 1 && s < S) a = (double)l0; }
-            else           { if (s >= S - 2 && s < S) a = (double)l0; }
-        }
-        ring[0][tid] = a;
-        asm volatile("" ::: "memory");
-        if (lane == 0) PIPE_FLAG_SET(tag[w], 1);
-        // emissions PIPE_LP frames ahead: every frame's row is a first touch of its cache line (used once by this workgroup), i.e. a
-        // trip to memory of ~1 us -- four frames ahead (~0.45 us at this kernel's pace) left the frame waiting for its emission
-        float lpq[PIPE_LP];
-#pragma unroll
-        for (int j = 0; j < PIPE_LP; ++j) lpq[j] = lp_at(1 + j);
-        // prefetched: the neighbour's counter and its edge pair of one frame, double-buffered by the frame's position in the unrolled
-        // group (static indices: no register copies at the joins, so the wait for a prefetch sits at its use, a whole frame later)
-        int tagq[2] = {0, 0}, consq[2] = {0, 0}; double eq0[2] = {-INFINITY, -INFINITY}, eq1[2] = {-INFINITY, -INFINITY};
-        // a wave without a neighbour (the first of alpha, the last of beta) follows its OWN counter -- always far enough -- and
-        // selects -inf: the frame is straight-line code for all four waves
-        const int nbw = has_nb ? nb : w;
-        const int eix = has_nb ? eidx : 0;
-#define PIPE_FETCH(buf, k_) do { consq[buf] = PIPE_FLAG_GET(consumed); tagq[buf] = PIPE_FLAG_GET(tag[nbw]); asm volatile("" ::: "memory"); \
-            const int slot_ = ((k_) - 1) & (PIPE_R - 1); eq0[buf] = PIPE_FLAG_GET(ring[slot_][eix]); eq1[buf] = PIPE_FLAG_GET(ring[slot_][eix + 1]); } while (0)
-        PIPE_FETCH(0, 1);
-#define PIPE_FRAME(buf, k_, lpc_) do { \
-            const int kk = (k_); \
-            const int cons = consq[buf];                                /* the storer's progress as of a frame ago: it only grows */ \
-            while (tagq[buf] < kk) { asm volatile("" ::: "memory"); PIPE_FETCH(buf, kk); }      /* frame k - 1 of the neighbour not finished yet */ \
-            const double E1 = has_nb ? (ROLE == 0 ? eq1[buf] : eq0[buf]) : -INFINITY;             /* alpha: states 64w-1, 64w-2; beta: 64(w+1), 64(w+1)+1 */ \
-            const double E2 = has_nb ? (ROLE == 0 ? eq0[buf] : eq1[buf]) : -INFINITY; \
-            /* the pair of frame k, wanted at the top of the next frame: in steady state the producer is a frame ahead and it is there */ \
-            PIPE_FETCH((buf) ^ 1, kk + 1); \
-            double p1, p2; \
-            if (diag & 16) { p1 = a + E1; p2 = a + E2; } else \
-            if (ROLE == 0) { p1 = dpp_f64<0x138>(E1, a); p2 = dpp_f64<0x138>(E2, p1); }      /* wave_shr:1 */ \
-            else           { p1 = dpp_f64<0x130>(E1, a); p2 = dpp_f64<0x130>(E2, p1); }      /* wave_shl:1 */ \
-            const double a2 = skip ? p2 : -INFINITY; \
-            const double v = ((diag & 2) ? fmax(a, fmax(p1, a2)) : lse3(a, p1, a2)) + (double)(lpc_); \
-            a = (s < S) ? v : -INFINITY; \
-            __builtin_amdgcn_sched_barrier(0); \
-            /* the slot held frame k - R: the storer must have read it */ \
-            if (cons < kk - PIPE_R + 1) { \
-                while (PIPE_FLAG_GET(consumed) < kk - PIPE_R + 1) asm volatile("" ::: "memory"); \
-            } \
-            ring[kk & (PIPE_R - 1)][tid] = a; \
-            asm volatile("" ::: "memory"); \
-            if (lane == 0) PIPE_FLAG_SET(tag[w], kk + 1); \
-        } while (0)
-        int k = 1;
-        for (; k + PIPE_LP - 1 < Tb; k += PIPE_LP) {
-#pragma unroll
-            for (int j = 0; j < PIPE_LP; ++j) { const float l_ = lpq[j]; lpq[j] = lp_at(k + j + PIPE_LP); PIPE_FRAME(j & 1, k + j, l_); }
-        }
-#pragma unroll
-        for (int j = 0; j < PIPE_LP - 1; ++j)
-            if (k + j < Tb) PIPE_FRAME(j & 1, k + j, lpq[j]);
-#undef PIPE_FRAME
-#undef PIPE_FETCH
-    }
-    __syncthreads();
-    if (ROLE == 0 && tid == 0) {
-        const double* rc = ring[(Tb - 1) & (PIPE_R - 1)];
-        const double ll = lse3(rc[S - 1], (S > 1) ? rc[S - 2] : -INFINITY, -INFINITY);
-        ws.nll64[b] = -ll;
-        nll_out[b] = (float)(-ll);
-    }
-}
-
-__global__ __launch_bounds__(CTC_THREADS + 64) void ctc_lattice_pipe_kernel(
-    const float* __restrict__ lp, const int32_t* __restrict__ targets,
-    const int32_t* __restrict__ in_len, const int32_t* __restrict__ tg_len,
-    int T, int B, int V, int Lmax, int Smax, int blank, CtcWs ws, float* __restrict__ nll_out, int diag) {
-    const int role = blockIdx.y;      // one uniform branch per workgroup, none per frame
-    if (role == 0) ctc_lattice_pipe_body<0>(lp, targets, in_len, tg_len, T, B, V, Lmax, blank, ws, nll_out, diag);
-    else if (role == 1) ctc_lattice_pipe_body<1>(lp, targets, in_len, tg_len, T, B, V, Lmax, blank, ws, nll_out, diag);
-    else ctc_labels_body(targets, tg_len, V, Lmax, Smax, blank, ws);
-}
-
 template <int NSPT>
 __global__ __launch_bounds__(CTC_THREADS + 64) void ctc_lattice_kernel(
     const float* __restrict__ lp, const int32_t* __restrict__ targets,
@@ -563,13 +383,7 @@ extern "C" int pgasr_ctc_loss_grad(const float* log_probs, const int32_t* target
     // one wave's fp64 VALU issue rate, not the barrier, is then the limit)
 #define PGASR_LATTICE(NSPT) PGASR_LAUNCH_KERNEL(ctc_lattice_kernel<NSPT>, dim3(B, 3), dim3(CTC_THREADS + 64), 0, st, \
                         log_probs, targets, input_lengths, target_lengths, T, B, V, Lmax > 0 ? Lmax : 1, Smax, blank, ws, nll, 0)
-    // PGASR_CTC_PIPE=1 (read at every call) selects the pipelined kernel for S <= 256 (A/B measurements; not faster so far)
-    const char* pe = getenv("PGASR_CTC_PIPE");
-    if (Smax <= CTC_THREADS && pe && pe[0] == '1')
-        PGASR_LAUNCH_KERNEL(ctc_lattice_pipe_kernel, dim3(B, 3), dim3(CTC_THREADS + 64), 0, st,
-                           log_probs, targets, input_lengths, target_lengths, T, B, V, Lmax > 0 ? Lmax : 1, Smax, blank, ws, nll,
-                           getenv("PGASR_CTC_DIAG") ? atoi(getenv("PGASR_CTC_DIAG")) : 0);
-    else if (Smax <= CTC_THREADS) PGASR_LATTICE(1);
+    if (Smax <= CTC_THREADS) PGASR_LATTICE(1);
     else if (Smax <= 2 * CTC_THREADS) PGASR_LATTICE(2);
     else if (Smax <= 4 * CTC_THREADS) PGASR_LATTICE(4);
     else PGASR_LATTICE(8);
