@@ -172,6 +172,7 @@ class InstNormAffineFn(torch.autograd.Function):
                     strideA=F * T, strideB=0, strideC=N, batch=B, bias=bias, act=1, slope=LEAKY_SLOPE,
                     norm_operand=1, shift=mean, scale=rstd, precision=0)
         ctx.save_for_backward(x, weight, mean, rstd, y)
+        ctx.bias_ref, ctx.weight_ref = bias, weight
         return y
 
     @staticmethod
@@ -184,6 +185,26 @@ class InstNormAffineFn(torch.autograd.Function):
             dpre = dy.contiguous()
         else:
             dpre = torch.where(y > 0, dy, dy * LEAKY_SLOPE).contiguous()
+        bg = getattr(ctx.bias_ref, "grad", None)
+        if grad_overlap.enabled and bg is not None and bg.is_contiguous() and bg.dtype == torch.float32:
+            # the tail of the step is ONE dependent chain by now: the bias gradient (two column-sum kernels, ~50 us) leaves it --
+            # accumulated straight into bias.grad on the side stream, beside the weight-gradient GEMM (joined by grad_overlap.finish)
+            main = torch.cuda.current_stream()
+            side = grad_overlap.side_stream()
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                hipops.colsum(dpre, T * B, N, N, bg, accumulate=True)
+            streams.hold(dpre, side)
+            wg = getattr(ctx.weight_ref, "grad", None)
+            direct = wg is not None and wg.is_contiguous() and wg.dtype == torch.float32 and tuple(wg.shape) == (N, F)
+            dW = wg if direct else torch.empty(N, F, dtype=torch.float32, device=x.device)
+            # .. and the weight gradient is summed into weight.grad by the GEMM's own slab reduction (one launch less on the chain)
+            hipops.gemm(dpre, x, dW, M=N, N=F, K=T, transA=True, transB=True, lda=B * N, ldb=T, ldc=F,
+                        strideA=N, strideB=F * T, strideC=0, batch=B, sum_batches=True, norm_operand=2,
+                        shift=mean, scale=rstd, accumulate=direct)
+            return (None, None if direct else dW, None, None)
         return (None, *InstNormAffineFn.param_grads(x, mean, rstd, dpre, N), None)
 
     @staticmethod

@@ -3,8 +3,8 @@
 The train step launches a fed sweep BEFORE the GEMM that produces its rows and lets the two run side by side; a counter-collecting
 profiler serialises kernels, so that order cannot be profiled.  Here the producer (pgasr_gemm_x3w_feed_f32, the same kernel and
 decomposition) runs FIRST, to completion, and the fed sweep (pgasr_lstm_layer_fwd_fed / _bwd_fed: the kernels of the timed step,
-helpers polling the tile counters, agent-scope loads of the fed rows, dropout mask applied by the backward helpers) then finds every
-tile counted complete.  What the counters see per sweep launch is the fed path's traffic without the wait."""
+helpers polling the tile counters, agent-scope loads of the fed rows, dropout mask applied by the backward helpers; the backward
+sweep also streamed: slab publications and L2 write-backs by its flusher workgroups) then finds every tile counted complete.  What the counters see per sweep launch is the fed path's traffic without the wait."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -36,7 +36,9 @@ for r in range(reps):
     dout = torch.empty(T, B, I, device=dev)
     done2 = torch.zeros(words, dtype=torch.int32, device=dev)
     hipops.gemm_x3w_feed(dg_above, planes_t, dout, T * B, I, G, None, 0, done2, order=1)
-    hipops.lstm_layer_bwd(gates, out, cbuf, dout, pb, lengths, T, B, want_dbias=True, fed=done2, fed_need=hipops.x3w_feed_col_tiles(I), drop=(0.3, 0x5EED, 3))
+    # .. and STREAMED, as in the timed step: the flusher workgroups write the XCD's L2 back once per time slab (nobody listens here)
+    slab = torch.zeros(64, dtype=torch.int32, device=dev)
+    hipops.lstm_layer_bwd(gates, out, cbuf, dout, pb, lengths, T, B, want_dbias=True, fed=done2, fed_need=hipops.x3w_feed_col_tiles(I), drop=(0.3, 0x5EED, 3), slab=slab)
 torch.cuda.synchronize()
 hipops.lstm_assert_no_timeouts()
 print("fed sweeps done", flush=True)
