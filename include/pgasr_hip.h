@@ -305,8 +305,10 @@ int pgasr_lstm_busy_offset(int B, int backward, size_t* offset);   /* 8 per-XCD 
 int pgasr_stream_gate(const unsigned* words, int count, int timeout_us, void* stream);
 /* The same for consumers that WAIT for the sweep (pgasr_lstm_wgrads_streamed): holds `stream` until the counters add up to
  * `need` = the sweep's clusters, 2 * ceil(B/16) -- all of its workgroups are then resident; workgroups that poll for the
- * sweep's publications must not take CUs the sweep still needs. */
-int pgasr_stream_gate_sum(const unsigned* words, int count, int need, int timeout_us, void* stream);
+ * sweep's publications must not take CUs the sweep still needs.  running (optional): the sweep's slab_done words -- a
+ * non-zero first word also opens the gate (the sweep has published, i.e. it is under way or already OVER: a gate that
+ * comes late would otherwise sit out its whole time-out on counters that have gone back to zero). */
+int pgasr_stream_gate_sum(const unsigned* words, int count, int need, const unsigned* running, int timeout_us, void* stream);
 /* One wave on `stream` waits (at most timeout_us <= 1e6) for words[0] != 0 and then writes words[1] = 1 if it saw it, else
  * 0.  Set words[0] from ANOTHER stream after this call: words[1] tells whether the two streams really run concurrently
  * (they do not under kernel-serialising profilers / launch-blocking modes / a single hardware queue).  The fed sweeps

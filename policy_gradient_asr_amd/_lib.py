@@ -77,7 +77,7 @@ SIGNATURES = {
     "pgasr_lstm_busy_offset": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "pgasr_lstm_status": (C.c_int, [c_ptr, C.c_size_t, C.c_int, C.c_int, c_ptr]),
     "pgasr_stream_gate": (C.c_int, [c_ptr, C.c_int, C.c_int, c_ptr]),
-    "pgasr_stream_gate_sum": (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
+    "pgasr_stream_gate_sum": (C.c_int, [c_ptr, C.c_int, C.c_int, c_ptr, C.c_int, c_ptr]),
     "pgasr_stream_probe": (C.c_int, [c_ptr, C.c_int, c_ptr]),
     "pgasr_lstm_layer_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int,
                                        c_f32p, C.c_float, C.c_uint64, C.c_uint32, c_ptr, C.c_size_t, c_ptr]),

@@ -1412,12 +1412,14 @@ extern "C" int pgasr_lstm_busy_offset(int B, int backward, size_t* offset) {
 namespace {
 // One wave that holds a stream back until a sweep has registered itself (any busy counter != 0) or the
 // time-out passes: gives "sweep first, GEMMs second" dispatch order across two streams.
-__global__ void __launch_bounds__(64) stream_gate_kernel(const unsigned* words, int count, unsigned need, long long timeout_ticks) {
+__global__ void __launch_bounds__(64) stream_gate_kernel(const unsigned* words, int count, unsigned need, const unsigned* running,
+                                                         long long timeout_ticks) {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();
     for (;;) {
         unsigned sum = 0;
         for (int i = 0; i < count; ++i) sum += __hip_atomic_load(words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (running && __hip_atomic_load(running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) sum = need;
         POLL_FENCE();
         if (sum >= need || wall_clock64() - t0 > timeout_ticks) break;
         __builtin_amdgcn_s_sleep(16);
@@ -1452,7 +1454,7 @@ extern "C" int pgasr_stream_probe(unsigned* words, int timeout_us, void* stream)
 
 extern "C" int pgasr_stream_gate(const unsigned* words, int count, int timeout_us, void* stream) {
     if (!words || count <= 0 || count > 64 || timeout_us < 0 || timeout_us > 100000) return PGASR_ERR_INVALID_ARG;
-    PGASR_LAUNCH_KERNEL(stream_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, count, 1u, (long long)timeout_us * 100);
+    PGASR_LAUNCH_KERNEL(stream_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, count, 1u, (const unsigned*)nullptr, (long long)timeout_us * 100);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }
@@ -1460,9 +1462,9 @@ extern "C" int pgasr_stream_gate(const unsigned* words, int count, int timeout_u
 // The same gate for consumers that WAIT for the sweep (pgasr_lstm_wgrads_streamed): holds `stream` until the busy counters add up to
 // `need` -- every cluster of the sweep has registered, i.e. all of its workgroups are resident -- since workgroups that poll for the
 // sweep's publications must not take CUs the sweep still needs.  Bounded like the other one (timeout_us <= 100000).
-extern "C" int pgasr_stream_gate_sum(const unsigned* words, int count, int need, int timeout_us, void* stream) {
+extern "C" int pgasr_stream_gate_sum(const unsigned* words, int count, int need, const unsigned* running, int timeout_us, void* stream) {
     if (!words || count <= 0 || count > 64 || need <= 0 || timeout_us < 0 || timeout_us > 100000) return PGASR_ERR_INVALID_ARG;
-    PGASR_LAUNCH_KERNEL(stream_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, count, (unsigned)need, (long long)timeout_us * 100);
+    PGASR_LAUNCH_KERNEL(stream_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, count, (unsigned)need, running, (long long)timeout_us * 100);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }

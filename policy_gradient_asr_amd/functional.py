@@ -434,6 +434,14 @@ class BLSTMLayerFn(torch.autograd.Function):
             grad_overlap.flush(busy, launched_after=before, first=(lambda: rec["launch"](busy)) if rec is not None else None)
             if rec is not None:
                 streams.hold(dout, grad_overlap.side_stream())
+            fed_done = None
+            if stream_own and grad_overlap._key() in grad_overlap._sides:
+                # the point of the side stream behind everything queued there for THIS sweep's time (the GEMM that feeds it, the
+                # head's weight gradients) and in FRONT of what the hook below may queue (N > 1: an all-reduce that waits for
+                # this sweep's end -- the streamed products must not wait for that)
+                fed_done = torch.cuda.Event()
+                with torch.cuda.stream(grad_overlap.side_stream()):
+                    fed_done.record()
             swept = torch.cuda.Event()
             swept.record()
             grad_overlap.note_event(swept)
@@ -552,16 +560,11 @@ class BLSTMLayerFn(torch.autograd.Function):
             # workgroups that wait for the sweep must not hold the CUs its producer needs (the sweep would wait for rows, the
             # products for the sweep: a circle until the time-outs); and the head's weight gradients beside the top layer's
             # sweep, which otherwise sit behind the waiting workgroups until the sweep ends and then delay the next feed
-            fed_done = None
-            if grad_overlap._key() in grad_overlap._sides:
-                fed_done = torch.cuda.Event()
-                with torch.cuda.stream(grad_overlap.side_stream()):
-                    fed_done.record()
             with torch.cuda.stream(s3):
                 s3.wait_event(before)            # the main stream just before the sweep; then ALL of the sweep's clusters must have registered
                 if fed_done is not None:
                     s3.wait_event(fed_done)
-                hipops.stream_gate(busy, need=2 * ((B + 15) // 16), timeout_us=5000)
+                hipops.stream_gate(busy, need=2 * ((B + 15) // 16), timeout_us=5000, running=slab)
                 dwih = torch.empty(G, I, dtype=torch.float32, device=dev)
                 dwhh = torch.empty(2, 4 * HID, HID, dtype=torch.float32, device=dev)
                 hipops.lstm_wgrads(dg, x, out, T, B, I, dwih, dwhh, busy_ptr=busy if grad_overlap.confine else 0,

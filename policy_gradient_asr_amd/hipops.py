@@ -786,11 +786,12 @@ def streams_concurrent(other):
     return _concurrent[key]
 
 
-def stream_gate(words_ptr, count=8, timeout_us=60, need=0):
+def stream_gate(words_ptr, count=8, timeout_us=60, need=0, running=None):
     """Hold the current stream until a sweep has registered in the busy counters at ``words_ptr``; need > 0: until ``need``
-    clusters have (consumers that wait for the sweep's publications: all of its workgroups must be resident first)."""
+    clusters have (consumers that wait for the sweep's publications: all of its workgroups must be resident first) -- or until
+    the first word of ``running`` (the streamed sweep's slab_done words) is non-zero: the sweep is under way or already over."""
     lib = _lib.load()
     if need > 0:
-        _lib.check(lib.pgasr_stream_gate_sum(words_ptr, count, int(need), timeout_us, _stream()), "pgasr_stream_gate_sum")
+        _lib.check(lib.pgasr_stream_gate_sum(words_ptr, count, int(need), _p(running), timeout_us, _stream()), "pgasr_stream_gate_sum")
     else:
         _lib.check(lib.pgasr_stream_gate(words_ptr, count, timeout_us, _stream()), "pgasr_stream_gate")

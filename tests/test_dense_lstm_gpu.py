@@ -369,7 +369,8 @@ def test_streamed_backward_sweep_feeds_its_own_weight_gradients(T, B, lens, flag
         want_hh0 = d64[1:, :, :4 * H].reshape(-1, 4 * H).t() @ o64[:-1, :, :H].reshape(-1, H)
         want_hh1 = d64[:-1, :, 4 * H:].reshape(-1, 4 * H).t() @ o64[1:, :, H:].reshape(-1, H)
         assert rel_err(dwhh_ref[0].cpu(), want_hh0) < 2e-5 and rel_err(dwhh_ref[1].cpu(), want_hh1) < 2e-5
-        for rep in range(2):
+        import time
+        for rep in range(3):
             dg = gates0.clone()
             words = torch.zeros(64, dtype=torch.int32, device=dev)
             dwih = torch.full((G, 512), float("nan"), device=dev); dwhh = torch.full((2, 4 * H, H), float("nan"), device=dev)
@@ -377,11 +378,16 @@ def test_streamed_backward_sweep_feeds_its_own_weight_gradients(T, B, lens, flag
             before = torch.cuda.Event(); before.record()
             ws = hipops.lstm_layer_bwd(dg, out, cbuf, dyd, pb, ln, T, B, slab=words)
             busy = hipops.lstm_busy_ptr(T, B, True, dev)
+            if rep == 2:
+                torch.cuda.synchronize()        # a consumer that comes LATE: the sweep is over, its busy counters are back to zero --
+                t_late = time.perf_counter()    # the gate must open on the publications, not sit out its (here 100 ms) time-out
             with torch.cuda.stream(side):
                 side.wait_event(before)
-                hipops.stream_gate(busy, need=2 * ((B + 15) // 16), timeout_us=5000)
+                hipops.stream_gate(busy, need=2 * ((B + 15) // 16), timeout_us=100000 if rep == 2 else 5000, running=words)
                 hipops.lstm_wgrads(dg, xd, out, T, B, 512, dwih, dwhh, busy_ptr=busy, slab=words, err_ws=ws)
             torch.cuda.synchronize()
+            if rep == 2:
+                assert time.perf_counter() - t_late < 0.05
             hipops.lstm_check_error(ws, B, True)
             nc = 2 * ((B + 15) // 16)
             assert words[:nc].tolist() == [len(edges) - 1] * nc

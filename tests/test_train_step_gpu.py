@@ -460,6 +460,22 @@ def test_upper_bucket_is_complete_where_its_allreduce_is_issued(B, T):
         assert split == tr.param_offset("encoder.blstm.weight_ih_l1") == FLAG_PAD + 512 * 80 + 512 + 2 * (1024 * (512 + 256) + 2048)
         assert torch.equal(snap, tr.gflat[split:])
         assert float(snap.abs().sum()) > 0 and float(tr.gflat[:split].abs().sum()) > 0
+    # .. and the collective order costs no time of its own: what is queued on the side stream for the end of the first layer's
+    # sweep (the all-reduce) must not hold back that layer's streamed products -- they once sat behind it and their gate then
+    # waited out its whole 5 ms time-out on busy counters that had gone back to zero
+    import time
+
+    def timed(n=6):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n):
+            tr.step(*batch)
+            snaps.clear()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    with_hook = timed()
+    tr.collective = False
+    without = timed()
+    assert with_hook < 1.5 * without + 1e-3, (with_hook, without)
 
 
 def test_two_bucket_allreduce_on_a_single_rank_rccl_group():

@@ -44,7 +44,7 @@ def run(mode):
         ws = hipops.lstm_layer_bwd(dg, out, cbuf, dy, pb, ln, T, B, slab=words); e1.record()
         with torch.cuda.stream(side):
             side.wait_event(e0)
-            hipops.stream_gate(busy, need=4, timeout_us=5000)
+            hipops.stream_gate(busy, need=4, timeout_us=5000, running=words)
             hipops.lstm_wgrads(dg, x, out, T, B, I, dwih, dwhh, busy_ptr=busy, slab=words, err_ws=ws)
             e2.record()
     elif mode == "plain+dW_beside_unrelated":
