@@ -125,7 +125,13 @@ extern "C" int pgasr_stream_copy(const void* src, void* dst, unsigned long long 
     if ((((size_t)src) | ((size_t)dst)) & 15) return PGASR_ERR_INVALID_ARG;
     const unsigned long long n16 = bytes / 16;
     const unsigned tail = (unsigned)(bytes % 16);
-    PGASR_LAUNCH_KERNEL(stream_copy_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const v4u*)src, (v4u*)dst, n16,
+    // The copy's workgroups must not share a CU with anybody's dependent chain (a sweep member, a lattice workgroup): a CU that
+    // also serves eight 16-byte host reads per lane slows its other tenant, and a sweep is as slow as its slowest member.  An LDS
+    // reservation nobody else leaves room for makes the dispatcher pick an otherwise idle CU (PGASR_COPY_LDS=0: no reservation).
+    static const int copy_lds = [] { const char* e = getenv("PGASR_COPY_LDS"); return e ? atoi(e) : 156 * 1024; }();
+    if (copy_lds > 0 && hipFuncSetAttribute((const void*)stream_copy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, copy_lds) != hipSuccess)
+        return PGASR_ERR_LAUNCH;
+    PGASR_LAUNCH_KERNEL(stream_copy_kernel, dim3(workgroups), dim3(256), (size_t)(copy_lds > 0 ? copy_lds : 0), (hipStream_t)stream, (const v4u*)src, (v4u*)dst, n16,
                        (const unsigned char*)src + n16 * 16, (unsigned char*)dst + n16 * 16, tail);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
