@@ -26,7 +26,7 @@ nb = lib.pgasr_lstm_workspace_bytes(T, B, 0)
 hello = ws[256:256 + 4 * 64 * 4].view(torch.int32).view(4, 64)[:, :16].cpu()     # 64 words per cluster, the first 16 are the members'
 print("XCC id per cluster member (rows = clusters):")
 print((hello & 0xF).tolist())
-hw = (hello >> 4) & 0xFF      # since round 3: [31:12] launch tag, [11:4] low bits of HW_REG_HW_ID, [3:0] XCD
+hw = (hello >> 16) & 0xFFFF
 print("CU id (HW_ID[11:8]) / SH / SE per member:")
 for r in range(4):
     print([f"se{(int(v) >> 13) & 7}.sh{(int(v) >> 12) & 1}.cu{(int(v) >> 8) & 15}" for v in hw[r].tolist()])
