@@ -78,3 +78,27 @@ def test_roofline_record_counts_launches_per_sampled_step():
     assert abs(rl["avg_launch_ms"] - 1.30) < 1e-12
     assert abs(rl["flops_per_launch"] - 2 * 2 * 32 * 256 * 1024 * 1000) < 1
     assert abs(rl["achieved"] - rl["flops_per_launch"] / 1.30e-3 / 1e12) < 1e-9 and abs(rl["peak"] - 2500 / 3) < 1e-9
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r03_bench.json is one line of `python bench.py` on an MI355X: the driver's contract fields, the roofline and CPU
+    baseline objects, and the round's extra legs are all there and consistent with each other."""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6           # utterances/sec of B = 32 per GPU
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] > 0
+    assert r["launches_per_step"] == 3.0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    for leg in ("long_run", "inputs_resident", "bucketed", "precision_variants", "max_rel_err_vs_fp64"):
+        assert leg in d, leg
+    assert d["inputs_resident"]["ms_per_step"] <= d["long_run"]["ms_per_step"] * 1.02      # staging costs time, never saves it
+    assert d["max_rel_err_vs_fp64"]["param_grads_maxnorm"] < 1e-3 and d["max_rel_err_vs_fp64"]["loss"] < 1e-3
+    pv = d["precision_variants"]
+    assert pv["f32"]["max_rel_err_vs_fp64"]["param_grads_frobenius"] < pv["bf16x3"]["max_rel_err_vs_fp64"]["param_grads_frobenius"]
