@@ -327,6 +327,8 @@ def test_blstm_fed_by_concurrent_projection_matches_sequential(T, B, lens):
     (1000, 32, [1000] * 20 + list(range(999, 987, -1)), 0),   # the headline length: 11 slabs
     (130, 32, [130] * 9 + list(range(129, 106, -1)), 0),    # very ragged
     (20, 32, [20] * 32, 0),                                 # a single slab
+    (2, 32, [2] * 20 + [1] * 12, 0),                        # the shortest sweep the products take: dW_hh sums ONE frame pair
+    (997, 32, [997] * 5 + list(range(996, 969, -1)), 0),    # a length that no slab size divides (configs[4]'s ragged batches)
     (200, 32, [200] * 32, 1),                               # write-through protocol: the storer waves release their own stores
 ])
 def test_streamed_backward_sweep_feeds_its_own_weight_gradients(T, B, lens, flags):
