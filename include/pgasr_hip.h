@@ -37,6 +37,8 @@ typedef enum pgasr_status {
     PGASR_ERR_TIMEOUT = 5        /* a bounded in-kernel wait gave up (persistent LSTM) */
 } pgasr_status;
 
+/* 4 (round 3): pgasr_adam_step(guards, applied), pgasr_lstm_pack_weights(planes), the feed phases, and the streamed order:
+ * pgasr_lstm_wgrad_slabs, pgasr_lstm_layer_bwd_streamed, pgasr_lstm_wgrads_streamed(+_workspace_bytes), pgasr_stream_gate_sum. */
 #define PGASR_ABI_VERSION 4
 
 int pgasr_abi_version(void);
