@@ -228,7 +228,8 @@ def test_edit_distance_reference_table(ops, dev, golden_dir):
     assert list(d.cpu().numpy()) == [w for _, _, w in pairs]
 
 
-@pytest.mark.parametrize("N,R,Hy,alpha", [(7, 1, 1, 2), (33, 70, 90, 4), (64, 100, 300, 28), (5, 500, 40, 3), (3, 1200, 700, 5)])
+@pytest.mark.parametrize("N,R,Hy,alpha", [(7, 1, 1, 2), (33, 70, 90, 4), (64, 100, 300, 28), (5, 500, 40, 3), (3, 1200, 700, 5),
+                                          (300, 40, 60, 6)])     # more than 128 pairs: the bulk path, many waves per CU (no LDS reservation)
 def test_edit_distance_random_and_prefix(ops, dev, N, R, Hy, alpha):
     rng = np.random.default_rng(N * R)
     ref = rng.integers(1, alpha + 1, size=(N, R)).astype(np.int32)
