@@ -39,7 +39,7 @@ typedef enum pgasr_status {
 
 /* 4 (round 3): pgasr_adam_step(guards, applied), pgasr_lstm_pack_weights(planes), the feed phases, and the streamed order:
  * pgasr_lstm_wgrad_slabs, pgasr_lstm_layer_bwd_streamed, pgasr_lstm_wgrads_streamed(+_workspace_bytes), pgasr_stream_gate_sum. */
-#define PGASR_ABI_VERSION 4
+#define PGASR_ABI_VERSION 5
 
 int pgasr_abi_version(void);
 const char* pgasr_status_string(int status);
@@ -150,7 +150,10 @@ int pgasr_reinforce_grad(const float* scores, const int32_t* path, const float* 
  *   the tile is loaded: the per-utterance InstanceNorm2d of model.py:37,48 fused into the affine.
  *   precision 0: exact fp32 MFMA.  precision 1: each operand element is split into bf16 hi+lo while
  *   staged and the product is hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation
- *   (~1e-6 relative; ~5x the fp32 matrix rate).
+ *   (~1e-6 relative; ~5x the fp32 matrix rate).  precision 2 (ABI 5): the fp32-faithful six-product arithmetic of
+ *   pgasr_gemm_x6w_f32 (three bf16 planes per operand) -- only for the weight-gradient shaped products the 256 x 256 TN
+ *   kernel takes (transA, !transB, split-K or batch sums, M, N % 256 == 0, K and the K-slabs % 32 == 0), else
+ *   PGASR_ERR_UNSUPPORTED.
  *   xcc_busy (NULL = plain launch; precision 1 only): device array of 8 words, e.g. the busy counters a
  *   persistent LSTM sweep keeps in its workspace (pgasr_lstm_busy_offset).  Tiles are then drawn from a
  *   global queue and a workgroup that RUNS on XCD i (HW_REG_XCC_ID) with xcc_busy[i] != 0 takes none; an
@@ -230,11 +233,38 @@ int pgasr_gemm_x3w_feed_f32(int M, int N, int K, const float* A, int lda, const 
  * any rest).  err_word (optional): set to 1 when a wait gives up after 3 s -- pass the sweep workspace's error word.
  * Needs in_dim % 256 == 0, B % 32 == 0, T >= 2 and 16-byte aligned tensors, else PGASR_ERR_UNSUPPORTED (use pgasr_gemm_f32
  * behind the sweep). */
+/* planes (ABI 5): 2 = the bf16x3 arithmetic above; 3 = the fp32-faithful six-product arithmetic of pgasr_gemm_x6w_f32 (csrc/gemm_x6.hip:
+ * 16-deep steps, three planes per operand), same slabs, same order, same gate. */
 size_t pgasr_lstm_wgrads_workspace_bytes(int T, int in_dim);
 int pgasr_lstm_wgrads_streamed(const float* dgates, const float* x, const float* out, int T, int B, int in_dim,
                                float* dwih_perm, float* dwhh_perm, const unsigned* xcc_busy,
-                               const unsigned* slab_done, int* err_word,
+                               const unsigned* slab_done, int* err_word, int planes,
                                void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same two roles of W_ih (input projection, input gradient: model.py:39-44) in the REFERENCE'S arithmetic -- torch fp32 -- at
+ * bf16 MFMA rate (csrc/gemm_x6.hip; the host layer's "f32" precision mode): every fp32 operand as THREE bf16 planes
+ * (x = hi + mid + lo to 2^-24) and every product as the SIX terms hh + hm + mh + hl + lh + mm (all terms >= 2^-24 of the product),
+ * fp32 accumulate.  256 x 256 tile, 16-deep steps.
+ * pgasr_split_bf16_planes3: like pgasr_split_bf16_planes with the third plane.
+ * pgasr_gemm_x6w_f32: C[M,N] = A[M,K] * W[N,K]^T (+ bias[n]) (* (dact_y[m,n] > 0 ? 1 : slope)); needs K % 16 == 0, K >= 64,
+ *   N % 256 == 0, lda % 4 == 0, 16-byte aligned A / planes, M*ldc*4 < 2^32 and M*lda*4 < 2^32, else PGASR_ERR_UNSUPPORTED
+ *   (use pgasr_gemm_f32 precision 0).  One fp32 accumulation chain over K per tile.
+ * pgasr_gemm_x6w_feed_f32: the product FEEDING a sweep that is already running -- contract, call order, tiles_done / xcc_busy /
+ *   order / workspace exactly as pgasr_gemm_x3w_feed_f32 (phase 0; there is no head launch), N % 512 == 0, M*ldc*4 < 2^31;
+ *   fed_need of the consumer = pgasr_gemm_x6w_feed_col_tiles(N) = N / 512.  With pgasr_gemm_x6w_feed_workspace_bytes() the first
+ *   tiles of a K >= 1024 (K % 64 == 0) feed are fixed-order sums ((q0 + q1) + q2) + q3 of K-quarters computed in parallel; called
+ *   with xcc_busy = NULL before a plain sweep it is the sequential order of the same product with the same bits. */
+int pgasr_split_bf16_planes3(const float* src, int rows, int cols, int ld, int transpose,
+                             unsigned short* hi, unsigned short* mid, unsigned short* lo, void* stream);
+int pgasr_gemm_x6w_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
+                       const unsigned short* Wmid, const unsigned short* Wlo, float* C, int ldc, const float* bias,
+                       const float* dact_y, float slope, void* stream);
+size_t pgasr_gemm_x6w_feed_workspace_bytes(void);
+int pgasr_gemm_x6w_feed_col_tiles(int N);
+int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
+                            const unsigned short* Wmid, const unsigned short* Wlo, float* C, int ldc, const float* bias,
+                            const unsigned* xcc_busy, unsigned* tiles_done, int order,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 size_t pgasr_colsum_workspace_bytes(int rows, int cols);
 int pgasr_colsum_f32(const float* X, int rows, int cols, int ld, float* out, float* out2, int accumulate,

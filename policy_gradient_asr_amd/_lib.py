@@ -94,7 +94,14 @@ SIGNATURES = {
                                                 c_ptr, C.c_size_t, c_ptr]),
     "pgasr_lstm_wgrads_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "pgasr_lstm_wgrads_streamed": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_ptr,
-                                             c_ptr, c_ptr, c_ptr, C.c_size_t, c_ptr]),
+                                             c_ptr, c_ptr, C.c_int, c_ptr, C.c_size_t, c_ptr]),
+    "pgasr_split_bf16_planes3": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "pgasr_gemm_x6w_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_ptr, c_ptr, c_ptr, c_f32p, C.c_int,
+                                     c_f32p, c_f32p, C.c_float, c_ptr]),
+    "pgasr_gemm_x6w_feed_workspace_bytes": (C.c_size_t, []),
+    "pgasr_gemm_x6w_feed_col_tiles": (C.c_int, [C.c_int]),
+    "pgasr_gemm_x6w_feed_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_ptr, c_ptr, c_ptr, c_f32p, C.c_int,
+                                          c_f32p, c_ptr, c_ptr, C.c_int, c_ptr, C.c_size_t, c_ptr]),
 }
 
 
@@ -122,7 +129,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.pgasr_abi_version() != 4:
+    if lib.pgasr_abi_version() != 5:
         raise PgasrError("libpgasr_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -109,6 +109,8 @@ struct PgasrTn256Args {
 };
 bool pgasr_internal_tn256_ok(const PgasrTn256Args& a);
 int pgasr_internal_tn256_launch(PgasrTn256Args a, int masked_then_unmasked, hipStream_t st, const PgasrTn256Args* second = nullptr);
+// the same contract in the six-product arithmetic (three bf16 planes per operand, 16-deep steps): gemm_x6.hip
+int pgasr_internal_tn6_launch(PgasrTn256Args a, int masked_then_unmasked, hipStream_t st, const PgasrTn256Args* second = nullptr);
 
 // ---- internal: the 8-wave 256 x 256 x3w kernel of gemm_c256.hip (cooperative A split), reached through pgasr_gemm_x3w_f32 / _feed_f32 ----
 struct PgasrX3cArgs {

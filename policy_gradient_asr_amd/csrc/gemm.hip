@@ -687,7 +687,7 @@ static int gemm_launch(GemmArgs& g, int transA, int transB, int sum_batches, int
                        size_t workspace_bytes, hipStream_t st) {
     const int Z = g.batch * g.splitk;
     const bool use_partial = (g.splitk > 1) || sum_batches;
-    const bool queue_mode = precision == 1 && xcc_busy != nullptr;
+    const bool queue_mode = precision >= 1 && xcc_busy != nullptr;
     const size_t head = 256;   // the first 256 workspace bytes hold the tile counter of queue mode
     if (use_partial || queue_mode) {
         const size_t need = head + (use_partial ? (size_t)Z * g.M * g.N * sizeof(float) : 0);
@@ -707,18 +707,19 @@ static int gemm_launch(GemmArgs& g, int transA, int transB, int sum_batches, int
     // weight-gradient shaped TN products (both operands k-major fp32, K long, split over K): the 256 x 256 LDS-DMA tile
     // of gemm_dma.hip writes the same raw partial slabs; the reduce below is shared
     bool done_tn256 = false;
-    if (precision == 1 && transA && !transB && use_partial && g.norm_operand == 0) {
+    if (precision >= 1 && transA && !transB && use_partial && g.norm_operand == 0) {
         PgasrTn256Args t{g.A, g.B, g.partial, g.M, g.N, g.K, g.lda, g.ldb, g.sA, g.sB, g.batch, g.splitk, g.kper, g.alpha,
                          queue_mode ? g.queue : nullptr, queue_mode ? g.xcc_busy : nullptr, getenv("PGASR_TN_DIAG") ? atoi(getenv("PGASR_TN_DIAG")) : 0,
                          nullptr, nullptr, 0, 0, 0, 0, nullptr};     // no gate, no time slabs
         if (pgasr_internal_tn256_ok(t)) {
-            const int st_ = pgasr_internal_tn256_launch(t, queue_mode ? 1 : 0, st);
+            const int st_ = precision == 2 ? pgasr_internal_tn6_launch(t, queue_mode ? 1 : 0, st) : pgasr_internal_tn256_launch(t, queue_mode ? 1 : 0, st);
             if (st_ != PGASR_OK) return st_;
             done_tn256 = true;
         }
     }
     if (done_tn256) {
     }
+    else if (precision == 2) return PGASR_ERR_UNSUPPORTED;      // the six-product arithmetic exists for the 256 x 256 TN shapes only
     else if (precision == 1) {
         if (queue_mode) {
             // pass 0: masked, enough workgroups that the allowed XCDs alone can cover every tile under
@@ -771,13 +772,13 @@ extern "C" int pgasr_gemm_f32(int transA, int transB, int M, int N, int K, float
                               int precision, const unsigned* xcc_busy, void* workspace, size_t workspace_bytes, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || splitk <= 0) return PGASR_ERR_INVALID_ARG;
     if (norm_operand < 0 || norm_operand > 2 || (norm_operand && (!shift || !scale))) return PGASR_ERR_INVALID_ARG;
-    if (act < 0 || act > 1 || precision < 0 || precision > 1) return PGASR_ERR_INVALID_ARG;
+    if (act < 0 || act > 1 || precision < 0 || precision > 2) return PGASR_ERR_INVALID_ARG;
     if ((splitk > 1 || sum_batches) && dact_y) return PGASR_ERR_INVALID_ARG;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.sA = strideA; g.sB = strideB; g.sC = strideC; g.batch = batch; g.splitk = splitk;
     int kper = (K + splitk - 1) / splitk;
-    const int kq = precision == 1 ? XBK : BK;
+    const int kq = precision >= 1 ? XBK : BK;
     kper = (kper + kq - 1) / kq * kq;
     g.kper = kper;
     g.alpha = alpha; g.bias = bias; g.bias2 = bias2; g.act = act; g.slope = slope; g.accumulate = accumulate;
@@ -805,10 +806,11 @@ extern "C" size_t pgasr_lstm_wgrads_workspace_bytes(int T, int in_dim) {
 }
 extern "C" int pgasr_lstm_wgrads_streamed(const float* dgates, const float* x, const float* out, int T, int B, int in_dim,
                                           float* dwih_perm, float* dwhh_perm, const unsigned* xcc_busy,
-                                          const unsigned* slab_done, int* err_word,
+                                          const unsigned* slab_done, int* err_word, int planes,
                                           void* workspace, size_t workspace_bytes, void* stream) {
     constexpr int H = 256, G = 2 * 4 * H;
     if (!dgates || !x || !out || !dwih_perm || !dwhh_perm || T <= 1 || B <= 0 || in_dim <= 0) return PGASR_ERR_INVALID_ARG;
+    if (planes != 2 && planes != 3) return PGASR_ERR_INVALID_ARG;
     const size_t need = pgasr_lstm_wgrads_workspace_bytes(T, in_dim);
     if (!workspace || workspace_bytes < need) return PGASR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -824,7 +826,7 @@ extern "C" int pgasr_lstm_wgrads_streamed(const float* dgates, const float* x, c
                       (unsigned*)workspace, xcc_busy, 0, slab_done, dgates, T, B, (B + 15) / 16, 1, err_word};
     if (!pgasr_internal_tn256_ok(ih) || !pgasr_internal_tn256_ok(hh)) return PGASR_ERR_UNSUPPORTED;
     if (hipMemsetAsync(workspace, 0, 256, st) != hipSuccess) return PGASR_ERR_LAUNCH;
-    const int rc = pgasr_internal_tn256_launch(ih, 1, st, &hh);
+    const int rc = planes == 3 ? pgasr_internal_tn6_launch(ih, 1, st, &hh) : pgasr_internal_tn256_launch(ih, 1, st, &hh);
     if (rc != PGASR_OK) return rc;
     PGASR_LAUNCH_KERNEL(gemm_reduce_kernel, dim3((unsigned)(((size_t)G * in_dim + 255) / 256), 1), dim3(256), 0, st,
                        part_ih, nslab, G, in_dim, dwih_perm, in_dim, (long long)0, (const float*)nullptr, (const float*)nullptr, 0, 0.f, 0);

@@ -441,6 +441,7 @@ __global__ __launch_bounds__(THREADS) void gemm_t256_kernel(PgasrTn256Args g0, P
     // lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3 of the group's 4 x 16 block; groups 0,1 take
     // columns 0-15 / 16-31 of k 0-7, groups 2,3 the same columns of k 8-15 (= the 32x32x16 operand map)
     const int tro = (8 * (lane >> 5) + ((lane & 15) >> 2)) * PITCH + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    bool gate_dead = false;      // GATED: the sweep's error word has been seen set (or a wait gave up): later items do not wait
   for (;;) {
     unsigned item;
     bool second = false;
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(THREADS) void gemm_t256_kernel(PgasrTn256Args g0, P
         k_beg = ra < 0 ? 0 : (int)ra; k_end = rb > g.K ? g.K : (int)rb;
         sidx = jj; z = bidx * g.splitk + sidx;
         if constexpr (GATED) {
-            if (tid < 64) {
+            if (tid < 64 && !gate_dead) {
                 const int t_lo = (row_off + k_beg) / g.gate_B, t_hi = (row_off + k_end - 1) / g.gate_B;
                 const int s_last = dir ? t_hi : T - 1 - t_lo;          // the last sweep step that writes one of these rows
                 unsigned need = 1;                                      // publication k covers sweep steps < T - h_(n-k)
@@ -498,11 +499,13 @@ __global__ __launch_bounds__(THREADS) void gemm_t256_kernel(PgasrTn256Args g0, P
                     unsigned v = need;
                     if (lane < g.gate_nbg) v = __hip_atomic_load(g.gate + 2 * lane + dir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (!__any(v < need)) break;
+                    // a sweep that gave up (its sticky error word) publishes nothing more: do not sit out 3 s per work item
+                    if (g.gate_err && __hip_atomic_load(g.gate_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { gate_dead = true; break; }
                     __builtin_amdgcn_s_sleep(32);
                     if (((++spins) & 255u) == 0) {
                         const long long now = wall_clock64();
                         if (spins == 256u) t0 = now;
-                        else if (now - t0 > 300000000LL) { if (g.gate_err) *g.gate_err = 1; break; }     // 3 s of the 100 MHz clock
+                        else if (now - t0 > 300000000LL) { if (g.gate_err) *g.gate_err = 1; gate_dead = true; break; }     // 3 s of the 100 MHz clock
                     }
                 }
             }

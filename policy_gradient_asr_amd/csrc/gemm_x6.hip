@@ -1,0 +1,698 @@
+// The path's big products in the REFERENCE'S OWN arithmetic (torch fp32: nn.LSTM's hoisted W_ih products, model.py:38-44) at
+// bf16-MFMA rate: every fp32 operand is split into THREE bf16 planes (hi, mid, lo: 8 + 8 + 8 mantissa bits, x = hi + mid + lo to
+// 2^-24) and a product is the SIX terms hh + hm + mh + hl + lh + mm -- every term down to 2^-24 of the product, fp32 accumulate;
+// the same split the recurrent sweeps' NP = 3 instantiation uses (lstm.hip).  This file is the "f32" precision mode's counterpart
+// of gemm_c256.hip (x3c: C = A W^T with pre-split W planes; t256: dW = dY^T X), so that the fp32-faithful step runs the same
+// feed-ahead and streamed orders as the bf16x3 one instead of 114-TF fp32-MFMA GEMMs in front of its sweeps.
+//
+// Both kernels keep gemm_c256.hip's 256 x 256 tile / 8 waves x (128 x 64) / one raw barrier per step, but a step is 16 deep:
+// six products on a 16-deep step are the 48 MFMAs per wave that three products on a 32-deep step were, the LDS image of a step
+// (three planes) is 3/4 of the old one, and the bytes a CU pulls per MFMA HALVE (40 KB per 48 MFMAs against 64 KB) -- the x3c
+// kernel sat at its CU's memory-path floor with the MFMA pipe 46 % busy, so the second three products are nearly free.
+//   x6c: A (fp32) loaded to registers THREE steps ahead (3 sets of 2 x 16 B per thread), split once per workgroup into the three
+//        LDS planes ([row][16 k] bf16, 32-byte rows, chunk ^= (row >> 3) & 1); W planes (pre-split, pgasr_split_bf16_planes3) by
+//        LDS-DMA into FOUR stages (three steps ahead): ~120 KB in flight per CU; hand-counted s_waitcnt vmcnt (5 memory
+//        instructions per wave and step: 3 W pieces, then 2 A loads).
+//   t6:  both operands fp32, k-major; registers two steps ahead (2 sets), planes in a k-major LDS image read with
+//        ds_read_b64_tr_b16; queue / time-slab / gated modes exactly as t256.
+// Results: one fp32 accumulation chain over K per tile (x6c; the feed's first tiles with K >= 1024: fixed-order K-quarter sums,
+// and the sequential order runs the same kernel -- same bits), slab sums in index order (t6).
+#include "common.h"
+#include "x3w_common.h"
+#include <type_traits>
+
+namespace {
+namespace x6c {
+constexpr int TM = 256, TN = 256, TK = 16, THREADS = 512;
+constexpr int NW = 4;                            // W stages in LDS: the DMA runs three steps ahead
+constexpr int NA = 3;                            // A register sets: the loads run three steps ahead of their conversion
+constexpr int AP_BYTES = TM * TK * 2;            // one A plane of one buffer: 8 KB
+constexpr int ABUF_BYTES = 3 * AP_BYTES;         // hi | mid | lo
+constexpr int WP_BYTES = TN * TK * 2;            // one W plane of one stage: 8 KB
+constexpr int WSTAGE_BYTES = 3 * WP_BYTES;       // hi | mid | lo
+constexpr int LDS_W = 2 * ABUF_BYTES;            // [A buffer 0][A buffer 1][W stage 0 .. 3][mailbox (FEED)]
+constexpr int LDS_BYTES = LDS_W + NW * WSTAGE_BYTES;     // 144 KB
+constexpr int SLAB_FLOATS = 128 * THREADS;       // one parked accumulator set: 256 KB
+
+typedef u32x4_t Planes2[2][3];                   // two 32-row tiles x (hi, mid, lo): 8 bf16 of one row each
+
+// fragment reads in inline asm: hipcc drains the LDS-DMA in flight (s_waitcnt vmcnt(0)) in front of any LDS access it can see
+__device__ __forceinline__ void read_pair(Planes2& o, unsigned p0, unsigned p1) {
+    static_assert(AP_BYTES == 8192 && WP_BYTES == 8192, "plane offsets are spelled in the asm below");
+    asm volatile("ds_read_b128 %0, %6\n\t"
+                 "ds_read_b128 %1, %6 offset:8192\n\t"
+                 "ds_read_b128 %2, %6 offset:16384\n\t"
+                 "ds_read_b128 %3, %7\n\t"
+                 "ds_read_b128 %4, %7 offset:8192\n\t"
+                 "ds_read_b128 %5, %7 offset:16384"
+                 : "=&v"(o[0][0]), "=&v"(o[0][1]), "=&v"(o[0][2]), "=&v"(o[1][0]), "=&v"(o[1][1]), "=&v"(o[1][2])
+                 : "v"(p0), "v"(p1)
+                 : "memory");
+}
+__device__ __forceinline__ void wait_pair(Planes2& o) {      // claims the registers the reads above are filling
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(o[0][0]), "+v"(o[0][1]), "+v"(o[0][2]), "+v"(o[1][0]), "+v"(o[1][1]), "+v"(o[1][2])
+                 :: "memory");
+}
+__device__ __forceinline__ void wait_pairs(Planes2& a, Planes2& b) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]),
+                   "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2])
+                 :: "memory");
+}
+// three 8-byte LDS stores (hi plane, mid = + 8 KB, lo = + 16 KB), hidden from hipcc like the reads
+__device__ __forceinline__ void write_planes3(unsigned addr, unsigned h0, unsigned h1, unsigned m0, unsigned m1, unsigned l0, unsigned l1) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u2;
+    const u2 h = {h0, h1}, m = {m0, m1}, l = {l0, l1};
+    asm volatile("ds_write_b64 %0, %1\n\t"
+                 "ds_write_b64 %0, %2 offset:8192\n\t"
+                 "ds_write_b64 %0, %3 offset:16384" :: "v"(addr), "v"(h), "v"(m), "v"(l) : "memory");
+}
+// A loads in inline asm: a load hipcc can see is waited for with s_waitcnt vmcnt(0) where its registers are handed to the asm
+// wait below -- which would also drain the W pieces in flight
+template <int J>
+__device__ __forceinline__ void load_a_one(u32x4_t (&r)[2], const unsigned (&aoff)[2], unsigned kb, const float* A) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r[J]) : "v"(aoff[J] + kb), "s"(A) : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void wait_a_regs(u32x4_t (&r)[2]) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r[0]), "+v"(r[1]) : "n"(CNT) : "memory");
+}
+
+// acc[i][j] += A_i x B_j as hh + hm + mh + hl + lh + mm, the two column tiles interleaved (no MFMA waits for its predecessor's result)
+__device__ __forceinline__ void mfma6(f32x16 (&acc)[2], const u32x4_t (&a)[3], const Planes2& b) {
+    constexpr int PA[6] = {0, 0, 1, 0, 2, 1}, PB[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[PA[p]]), __builtin_bit_cast(bf16x8_t, b[j][PB[p]]), acc[j], 0, 0, 0);
+}
+
+template <bool FEED>
+__global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];   // the ONLY LDS object
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 2, wn = w & 3;
+    const int nk = g.K / TK;
+    if (FEED && g.xcc_busy) {       // a workgroup on one of the sweep's XCDs leaves at once (placement is read, not assumed)
+        const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;
+        if (__hip_atomic_load(g.xcc_busy + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  for (;;) {
+    int tbx, tby;
+    int kt0 = 0, kt1 = nk, qpart = -1;      // step range of this work item; qpart >= 0: one quarter of a split tile
+    unsigned tile = 0;
+    if (FEED) {
+        unsigned* mailbox = reinterpret_cast<unsigned*>(smem + LDS_BYTES);
+        if (tid == 0) *mailbox = __hip_atomic_fetch_add(g.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned t = *mailbox;
+        __syncthreads();
+        const unsigned S = (unsigned)g.split_tiles, ntot = (unsigned)g.mt_count * (unsigned)g.nt_count;
+        if (t >= ntot + 3u * S) return;             // 4 S quarter items, then the remaining ntot - S whole tiles
+        if (t < 4u * S) { tile = t >> 2; qpart = (int)(t & 3u); kt0 = qpart * (nk >> 2); kt1 = kt0 + (nk >> 2); }
+        else tile = t - 3u * S;
+        const int half = g.nt_count >> 1, grp = (int)(tile / (unsigned)g.nt_count), j = (int)(tile % (unsigned)g.nt_count);
+        tbx = j;
+        tby = ((j < half) != (g.order != 0)) ? grp : g.mt_count - 1 - grp;
+    } else {
+        swizzled_tile(tbx, tby);
+    }
+    const int m0 = tby * TM, n0 = tbx * TN;
+
+    // ---- A: lane -> (row within a 16-row group, 16-byte chunk of the step's 64-byte row segment); wave w owns rows 32 w .. 32 w + 31
+    const int rsub = lane >> 2, ac = lane & 3;
+    unsigned aoff[2];           // byte offsets into A of (row, chunk) at k = 0 (rows past M clamped: their products are never stored)
+    unsigned apw[2];            // byte offsets into an A buffer (hi plane) of the 8 bytes this lane writes per row
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = w * 32 + j * 16 + rsub;
+        int gm = m0 + r; gm = gm < g.M ? gm : g.M - 1;
+        aoff[j] = (unsigned)(((size_t)gm * g.lda + ac * 4) * 4);
+        apw[j] = (unsigned)(r * 32 + (((ac >> 1) ^ ((r >> 3) & 1)) * 16) + (ac & 1) * 8);
+    }
+    // ---- W planes by LDS-DMA: piece = 32 rows x 32 B; wave w moves piece w of each plane
+    const unsigned short* pw[3];
+    {
+        const int row = 32 * w + (lane >> 1), cp = lane & 1, c = cp ^ ((row >> 3) & 1);
+        const size_t o = (size_t)(n0 + row) * g.K + c * 8;
+        pw[0] = g.Whi + o; pw[1] = g.Wmid + o; pw[2] = g.Wlo + o;
+    }
+    auto issue_w1 = [&](int kt, int stage, int plane) {     // one of a step's three W pieces
+        const int k0 = (kt < nk ? kt : nk - 1) * TK;
+        dma16(pw[plane] + k0, smem + LDS_W + stage * WSTAGE_BYTES + plane * WP_BYTES + w * 1024);
+    };
+    auto issue_w = [&](int kt, int stage) { issue_w1(kt, stage, 0); issue_w1(kt, stage, 1); issue_w1(kt, stage, 2); };
+    u32x4_t araw[NA][2];
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    auto load_a1 = [&](int kt, auto setc, int j) {      // ONE of a step's two A loads (k clamped: always issued, the counted waits are exact)
+        const unsigned kb = (unsigned)((kt < nk ? kt : nk - 1) * TK * 4);
+        if (j == 0) load_a_one<0>(araw[decltype(setc)::value], aoff, kb, g.A);
+        else load_a_one<1>(araw[decltype(setc)::value], aoff, kb, g.A);
+    };
+    auto load_a = [&](int kt, auto setc) { load_a1(kt, setc, 0); load_a1(kt, setc, 1); };
+    auto convert_a = [&](int buf, auto setc) {    // register set -> the three planes of buffer `buf`
+        constexpr int S = decltype(setc)::value;
+        const unsigned base = lds0 + (unsigned)buf * ABUF_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned h0, m0_, l0, h1, m1_, l1;
+            split3(__uint_as_float(araw[S][j].x), __uint_as_float(araw[S][j].y), h0, m0_, l0);
+            split3(__uint_as_float(araw[S][j].z), __uint_as_float(araw[S][j].w), h1, m1_, l1);
+            write_planes3(base + apw[j], h0, h1, m0_, m1_, l0, l1);
+        }
+    };
+
+    // ---- fragment read offsets (hi plane; mid / lo = + 8 KB / + 16 KB) ----
+    const int fr = lane & 31, fh = lane >> 5;
+    unsigned offA[4], offB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wm * 128 + i * 32 + fr;
+        offA[i] = (unsigned)(row * 32 + ((fh ^ ((row >> 3) & 1)) * 16));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = wn * 64 + j * 32 + fr;
+        offB[j] = (unsigned)(LDS_W + n * 32 + ((fh ^ ((n >> 3) & 1)) * 16));
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // one half of a step: row tiles 2 HALF, 2 HALF + 1 against both column tiles = 24 MFMAs; `mem(0)` runs behind the first
+    // twelve, `mem(1)` behind the last twelve (the step's five memory instructions are spread over its four twelve-MFMA
+    // blocks: a blocked issue behind 384 cycles of queued MFMA costs nothing, see gemm_c256.hip)
+    auto half_step = [&](int cur, int wst, auto halfc, Planes2& fb, auto&& mem) {
+        constexpr int HALF = decltype(halfc)::value;
+        const unsigned ab = lds0 + (unsigned)cur * ABUF_BYTES, wb = lds0 + (unsigned)wst * WSTAGE_BYTES;
+        Planes2 fa;
+        if (HALF == 0) read_pair(fb, wb + offB[0], wb + offB[1]);
+        read_pair(fa, ab + offA[2 * HALF], ab + offA[2 * HALF + 1]);
+        if (HALF == 0) wait_pairs(fa, fb); else wait_pair(fa);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            mfma6(acc[2 * HALF + i], fa[i], fb);
+            __builtin_amdgcn_sched_barrier(0);
+            mem(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- prologue: A planes of the first step; then, in the steady state's issue order, W(1) A(2) W(2) A(3) behind W(0) A(1) ----
+    load_a(kt0, I0{});
+    issue_w(kt0, 0);
+    wait_a_regs<3>(araw[0]);                      // the A loads (older than the 3 W pieces) are in
+    convert_a(0, I0{});
+    load_a(kt0 + 1, I1{});
+    issue_w(kt0 + 1, 1);
+    load_a(kt0 + 2, I2{});
+    issue_w(kt0 + 2, 2);
+    load_a(kt0 + 3, I0{});
+    asm volatile("s_waitcnt vmcnt(12)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");    // W stage 0 landed (my pieces), my plane stores done
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // one 16-deep step; SET = the register set that holds the A rows of step kt + 1.  In flight when the step starts, oldest first:
+    //   [A(kt+1) 2] [W(kt+1) 3] [A(kt+2) 2] [W(kt+2) 3] [A(kt+3) 2];   the step issues [W(kt+3) 3] in its first half, [A(kt+4) 2] in its second
+    typedef std::integral_constant<int, 1> H1;
+    auto step = [&](const int kt, auto setc) {
+        const int rel = kt - kt0, cur = rel & 1, wst = rel & (NW - 1);
+        const int kw = kt + NW - 1, sw = (rel + NW - 1) & (NW - 1);    // the W step issued now, into the stage everybody finished reading before the barrier just passed
+        auto mem_w = [&](int s) { if (s == 0) { issue_w1(kw, sw, 0); issue_w1(kw, sw, 1); } else issue_w1(kw, sw, 2); };
+        auto mem_a = [&](int s) { load_a1(kt + 1 + NA, setc, s); };
+        Planes2 fb;
+        __builtin_amdgcn_sched_barrier(0);
+        if (w < 4) {
+            wait_a_regs<10>(araw[decltype(setc)::value]);
+            convert_a(cur ^ 1, setc);
+            __builtin_amdgcn_sched_barrier(0);
+            half_step(cur, wst, I0{}, fb, mem_w);
+            half_step(cur, wst, H1{}, fb, mem_a);
+        } else {
+            half_step(cur, wst, I0{}, fb, mem_w);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_a_regs<13>(araw[decltype(setc)::value]);     // .. plus the three W pieces just issued
+            convert_a(cur ^ 1, setc);
+            __builtin_amdgcn_sched_barrier(0);
+            half_step(cur, wst, H1{}, fb, mem_a);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // my W pieces of step kt + 1 have landed (behind them: A(kt+2) W(kt+2) A(kt+3) W(kt+3) A(kt+4) = 12), my plane stores are done
+        asm volatile("s_waitcnt vmcnt(12)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    for (int kt = kt0; kt < kt1; kt += 3) {        // A(kt + 1) sits in set (kt - kt0 + 1) % 3
+        step(kt, I1{});
+        if (kt + 1 < kt1) step(kt + 1, I2{});
+        if (kt + 2 < kt1) step(kt + 2, I0{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the loads of the steps behind the last one (discarded)
+#pragma unroll
+    for (int s = 0; s < NA; ++s) asm volatile("" : "+v"(araw[s][0]), "+v"(araw[s][1]));
+
+    if (FEED && qpart >= 0) {
+        // one quarter of a split tile: park the accumulators (thread-major: a wave instruction stores 256 contiguous
+        // bytes) write-through, count the arrival; the LAST of the four sums the quarters in index order and goes on to
+        // the epilogue, the others take their next work item
+        __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(g.slabs, 0, (int)(unsigned)((size_t)g.split_tiles * 4 * SLAB_FLOATS * 4), 0x00020000);
+        const unsigned sbq = (tile * 4u + (unsigned)qpart) * 128u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), srs, ((sbq + (unsigned)((i * 2 + j) * 16 + r)) * 512u + (unsigned)tid) * 4u, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* mailbox = reinterpret_cast<unsigned*>(smem + LDS_BYTES);
+        if (tid == 0) *mailbox = __hip_atomic_fetch_add(g.arrive + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned before = *mailbox;
+        __syncthreads();
+        if (before != 3u) continue;
+        // total = ((q0 + q1) + q2) + q3, whoever arrives last
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                            srs, (((tile * 4u + (unsigned)qq) * 128u + (unsigned)((i * 2 + j) * 16 + r)) * 512u + (unsigned)tid) * 4u, 0, 16));
+                        t = qq == 0 ? v : t + v;
+                    }
+                    acc[i][j][r] = t;
+                }
+    }
+
+    // epilogue (branch-free): 32x32 accumulator layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int cl = lane & 31, rq = lane >> 5;
+    __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(unsigned)((size_t)g.M * g.ldc * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dact_y ? g.dact_y : g.C), 0, (int)(unsigned)((size_t)g.M * g.ldc * 4), 0x00020000);
+    float bsum[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bsum[j] = g.bias ? g.bias[n0 + wn * 64 + j * 32 + cl] : 0.f;
+    if (g.dact_y) {            // two straight-line loops: a merge point inside one brings a per-tile s_waitcnt vmcnt(0) back
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned o0 = (unsigned)(((size_t)(m0 + wm * 128 + i * 32 + 4 * rq) * g.ldc + n0 + wn * 64 + j * 32 + cl) * 4);
+                float f[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    f[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4), 0, 0)) > 0.f ? 1.f : g.slope;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((acc[i][j][r] + bsum[j]) * f[r]), crs, o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4), 0, FEED ? 16 : 0);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned o0 = (unsigned)(((size_t)(m0 + wm * 128 + i * 32 + 4 * rq) * g.ldc + n0 + wn * 64 + j * 32 + cl) * 4);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r] + bsum[j]), crs, o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4), 0, FEED ? 16 : 0);
+            }
+    }
+    if (!FEED) return;
+    // the tile's stores have reached memory (vmcnt(0) in every wave, then the barrier) before it is counted; the
+    // barrier also retires every DMA of this tile before the next one reuses the stages
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        __hip_atomic_fetch_add(g.tiles_done + (tbx < (g.nt_count >> 1) ? 0 : g.mt_count) + tby, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+}  // namespace x6c
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradients dW = dY^T X in the same arithmetic (model.py:39-44 backward: dW_ih = dgates^T x, dW_hh = dgates^T h_prev):
+// gemm_c256.hip's t256 kernel on 16-deep steps and three planes per operand.  Per step a thread loads 2 x 16 B of either
+// operand (a wave instruction = one 1-KB k-row), two steps ahead (two register sets), splits the 16 values into hi / mid / lo
+// and writes the six planes of the k-major image [k][256 + 32 pad] (pitch 576 B); fragments by ds_read_b64_tr_b16; two LDS
+// buffers of 54 KB; the two waves of a SIMD half a step out of phase.  Queue mode, time slabs, the gate on a running sweep's
+// slab_done words and the sc1 loads of its dgates: as in t256 (same PgasrTn256Args, same requirements).
+// ------------------------------------------------------------------------------------------------------------------
+namespace t6 {
+constexpr int TM = 256, TN = 256, TK = 16, THREADS = 512;
+constexpr int PITCH = 288;                        // halfs per k-row of a plane image (576 B)
+constexpr int PLANE_HALFS = TK * PITCH;           // 4608 halfs = 9 KB
+constexpr int BUF_HALFS = 6 * PLANE_HALFS;        // A hi | mid | lo | B hi | mid | lo = 54 KB
+constexpr int LDS_BYTES = 2 * BUF_HALFS * 2;      // 108 KB
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ bf16x8_t tr_frag(const unsigned short* p) {
+    typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_ptr;
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * PITCH));
+    return __builtin_bit_cast(bf16x8_t, (s16x8_t){a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w});
+}
+
+template <bool GATED>
+__global__ __launch_bounds__(THREADS) void gemm_t6_kernel(PgasrTn256Args g0, PgasrTn256Args g1) {
+    extern __shared__ __attribute__((aligned(128))) unsigned short S[];      // the ONLY LDS object: [buffer][A hi, mid, lo, B hi, mid, lo][k][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 2, wn = w & 3;
+    if (g0.queue && g0.xcc_busy) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;
+        if (__hip_atomic_load(g0.xcc_busy + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    }
+    const unsigned per0 = (unsigned)((g0.N / TN) * (g0.M / TM) * g0.batch), per1 = g1.M > 0 ? (unsigned)((g1.N / TN) * (g1.M / TM) * g1.batch) : 0u;
+    const unsigned nitems_all = (per0 + per1) * (unsigned)g0.splitk;
+    // the 32x32x16 operand map of a transposing read (see t256)
+    const int tro = (8 * (lane >> 5) + ((lane & 15) >> 2)) * PITCH + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    bool gate_dead = false;      // GATED: the sweep's error word has been seen set: it publishes nothing more, later items do not wait
+  for (;;) {
+    unsigned item;
+    bool second = false;
+    if (g0.queue) {
+        unsigned* mailbox = reinterpret_cast<unsigned*>(S);       // the buffers are idle between two items
+        if (tid == 0) *mailbox = __hip_atomic_fetch_add(g0.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        item = (unsigned)__builtin_amdgcn_readfirstlane((int)*mailbox);
+        __syncthreads();
+        if (item >= nitems_all) return;
+        if (per1) {
+            const unsigned jj = item / (per0 + per1), r = item % (per0 + per1);
+            second = r >= per0;
+            item = second ? jj * per1 + (r - per0) : jj * per0 + r;
+        }
+    }
+    const PgasrTn256Args g = second ? g1 : g0;
+    const int tx = g.N / TN, ty = g.M / TM;
+    const unsigned nitems = (unsigned)(tx * ty) * (unsigned)(g.batch * g.splitk);
+    if (!g0.queue) {
+        // plain launch: whole K-slabs per XCD (see t256)
+        const unsigned per = (unsigned)(tx * ty), nslab = (unsigned)(g.batch * g.splitk);
+        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        const unsigned zz = xcd + 8u * (j / per);
+        item = (nitems % (8u * per) == 0u && nslab % 8u == 0u) ? zz * per + j % per : blockIdx.x;
+    }
+    if (item >= nitems) return;
+    int z = (int)(item / (unsigned)(tx * ty)), t2 = (int)(item % (unsigned)(tx * ty));
+    int bidx = z / g.splitk, sidx = z % g.splitk;
+    int k_beg = sidx * g.kper, k_end = (k_beg + g.kper < g.K) ? k_beg + g.kper : g.K;
+    if (g.tslabs) {
+        // item = (time slab in the order a backward sweep completes them, batch, tile); see pgasr_wslab_edge (common.h)
+        const unsigned per = (unsigned)(tx * ty * g.batch);
+        const int jj = (int)(item / per), rem = (int)(item % per);
+        bidx = rem / (tx * ty); t2 = rem % (tx * ty);
+        const long long off = (long long)(g.A - g.gate_base) + (long long)bidx * g.sA + (long long)(t2 / tx) * TM;
+        const int row_off = (int)(off / g.lda), dir = (off % g.lda) >= g.lda / 2 ? 1 : 0;
+        const int n = g.splitk, T = g.gate_T;
+        const int h_lo = pgasr_wslab_edge(T, n - jj - 1), h_hi = pgasr_wslab_edge(T, n - jj);
+        const long long ra_ = (long long)(dir ? T - h_hi : h_lo) * g.gate_B - row_off, rb_ = (long long)(dir ? T - h_lo : h_hi) * g.gate_B - row_off;
+        k_beg = ra_ < 0 ? 0 : (int)ra_; k_end = rb_ > g.K ? g.K : (int)rb_;
+        sidx = jj; z = bidx * g.splitk + sidx;
+        if constexpr (GATED) {
+            if (tid < 64 && !gate_dead) {
+                const int t_lo = (row_off + k_beg) / g.gate_B, t_hi = (row_off + k_end - 1) / g.gate_B;
+                const int s_last = dir ? t_hi : T - 1 - t_lo;          // the last sweep step that writes one of these rows
+                unsigned need = 1;                                      // publication k covers sweep steps < T - h_(n-k)
+                while ((int)need < n && T - pgasr_wslab_edge(T, n - (int)need) <= s_last) ++need;
+                unsigned spins = 0; long long t0 = 0;
+                while (true) {
+                    asm volatile("" ::: "memory");
+                    unsigned v = need;
+                    if (lane < g.gate_nbg) v = __hip_atomic_load(g.gate + 2 * lane + dir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!__any(v < need)) break;
+                    // a sweep that gave up (its sticky error word) publishes nothing more: do not sit out 3 s per item
+                    if (g.gate_err && __hip_atomic_load(g.gate_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { gate_dead = true; break; }
+                    __builtin_amdgcn_s_sleep(32);
+                    if (((++spins) & 255u) == 0) {
+                        const long long now = wall_clock64();
+                        if (spins == 256u) t0 = now;
+                        else if (now - t0 > 300000000LL) { if (g.gate_err) *g.gate_err = 1; gate_dead = true; break; }     // 3 s of the 100 MHz clock
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int tbx = t2 % tx, tby = t2 / tx;
+    const int nk = (k_end - k_beg) / TK;               // >= 2 (pgasr_internal_tn256_ok: no empty slab, slabs are multiples of 32)
+    const int m0 = tby * TM, n0 = tbx * TN;
+    // wave w loads k-rows 2 w + j (j = 0, 1) of both operands: one 1-KB row per wave instruction
+    const float* Ab = g.A + (size_t)bidx * g.sA + (size_t)(k_beg + 2 * w) * g.lda + m0 + 4 * lane;
+    const float* Bb = g.B + (size_t)bidx * g.sB + (size_t)(k_beg + 2 * w) * g.ldb + n0 + 4 * lane;
+    f32x4_t ra[2][2], rb[2][2];                         // [register set][k-row]
+    __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + (size_t)bidx * g.sA + (size_t)k_beg * g.lda + m0), 0,
+                                                                   GATED ? (int)((size_t)nk * TK * g.lda * 4) : 0, 0x00020000);
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    auto load = [&](int kt, auto setc) {
+        constexpr int s = decltype(setc)::value;
+        const int kc = kt < nk ? kt : nk - 1;          // past the slab: reload the last step (never converted)
+        const float* pa = Ab + (size_t)kc * TK * g.lda;
+        const float* pb = Bb + (size_t)kc * TK * g.ldb;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (GATED) {
+                const u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(ars, (unsigned)(((size_t)(kc * TK + 2 * w + j) * g.lda + 4 * lane) * 4), 0, 16);
+                ra[s][j] = __builtin_bit_cast(f32x4_t, u);
+            } else {
+                ra[s][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(pa + (size_t)j * g.lda));
+            }
+            rb[s][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(pb + (size_t)j * g.ldb));
+        }
+    };
+    auto convert = [&](int buf, auto setc) {
+        constexpr int s = decltype(setc)::value;
+        unsigned short* base = S + buf * BUF_HALFS + (2 * w) * PITCH + 4 * lane;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned h0, m0_, l0, h1, m1_, l1;
+            split3(ra[s][j].x, ra[s][j].y, h0, m0_, l0); split3(ra[s][j].z, ra[s][j].w, h1, m1_, l1);
+            *reinterpret_cast<u32x2_t*>(base + j * PITCH) = (u32x2_t){h0, h1};
+            *reinterpret_cast<u32x2_t*>(base + PLANE_HALFS + j * PITCH) = (u32x2_t){m0_, m1_};
+            *reinterpret_cast<u32x2_t*>(base + 2 * PLANE_HALFS + j * PITCH) = (u32x2_t){l0, l1};
+            split3(rb[s][j].x, rb[s][j].y, h0, m0_, l0); split3(rb[s][j].z, rb[s][j].w, h1, m1_, l1);
+            *reinterpret_cast<u32x2_t*>(base + 3 * PLANE_HALFS + j * PITCH) = (u32x2_t){h0, h1};
+            *reinterpret_cast<u32x2_t*>(base + 4 * PLANE_HALFS + j * PITCH) = (u32x2_t){m0_, m1_};
+            *reinterpret_cast<u32x2_t*>(base + 5 * PLANE_HALFS + j * PITCH) = (u32x2_t){l0, l1};
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // one half of a step: row tiles 2 HALF, 2 HALF + 1 against both column tiles = 24 MFMAs (hh + hm + mh + hl + lh + mm)
+    auto multiply = [&](int buf, auto halfc, bf16x8_t (&bf)[2][3]) {
+        constexpr int HALF = decltype(halfc)::value;
+        const unsigned short* img = S + buf * BUF_HALFS + tro;
+        if (HALF == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bf[j][p] = tr_frag(img + (3 + p) * PLANE_HALFS + wn * 64 + j * 32);
+        }
+        bf16x8_t af[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[i][p] = tr_frag(img + p * PLANE_HALFS + wm * 128 + (2 * HALF + i) * 32);
+        constexpr int PA[6] = {0, 0, 1, 0, 2, 1}, PB[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[2 * HALF + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[p]], bf[j][PB[p]], acc[2 * HALF + i][j], 0, 0, 0);
+    };
+    // a raw barrier: __syncthreads() would also wait (vmcnt) for the loads of the steps ahead that are in flight
+#define T6_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+    load(0, I0{});
+    convert(0, I0{});
+    load(1, I1{});
+    load(2, I0{});
+    T6_BARRIER();
+    const bool mem = !(g.diag & 1), mul = !(g.diag & 2);
+    auto step = [&](int kt, auto setc) {               // setc: the register set that holds step kt + 1
+        const int cur = kt & 1;
+        bf16x8_t bf[2][3];
+        if (w < 4) {
+            if (mem) { if (kt + 1 < nk) convert(cur ^ 1, setc); load(kt + 3, setc); }
+            if (mul) { multiply(cur, I0{}, bf); multiply(cur, I1{}, bf); }
+        } else {
+            if (mul) multiply(cur, I0{}, bf);
+            if (mem) { if (kt + 1 < nk) convert(cur ^ 1, setc); load(kt + 3, setc); }
+            if (mul) multiply(cur, I1{}, bf);
+        }
+        T6_BARRIER();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, I1{});
+        if (kt + 1 < nk) step(kt + 1, I0{});
+    }
+#undef T6_BARRIER
+
+    // raw alpha * acc into this item's slab (branch-free buffer stores)
+    float* slab = g.partial + (size_t)z * g.M * g.N;
+    __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)(unsigned)((size_t)g.M * g.N * 4), 0x00020000);
+    const int cl = lane & 31, rq = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned o0 = (unsigned)(((size_t)(m0 + wm * 128 + i * 32 + 4 * rq) * g.N + n0 + wn * 64 + j * 32 + cl) * 4);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(g.alpha * acc[i][j][r]), prs, o0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.N * 4), 0, 0);
+        }
+    if (!g0.queue) return;
+    __syncthreads();           // every read of this item's last buffer is done before the mailbox / the next item's images are written
+  }
+}
+}  // namespace t6
+
+// fp32 (rows x cols, leading dim ld) -> dense bf16 hi / mid / lo planes; transpose: planes are (cols x rows)
+__global__ __launch_bounds__(256) void split_planes3_kernel(const float* __restrict__ src, int rows, int cols, int ld,
+                                                            int transpose, unsigned short* __restrict__ hi,
+                                                            unsigned short* __restrict__ mid, unsigned short* __restrict__ lo) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)rows * cols) return;
+    int r, c;
+    if (transpose) { c = (int)(idx / rows); r = (int)(idx % rows); }     // output index = c*rows + r
+    else { r = (int)(idx / cols); c = (int)(idx % cols); }
+    unsigned h, m, l;
+    split3(src[(size_t)r * ld + c], 0.f, h, m, l);
+    hi[idx] = (unsigned short)h;
+    mid[idx] = (unsigned short)m;
+    lo[idx] = (unsigned short)l;
+}
+
+constexpr int X6_FEED_SPLIT_MAX = 32;      // split tiles per feed: 4 x 32 slabs of 256 KB = 32 MB of workspace
+int x6_quarters(int K) { return (K >= 1024 && K % (4 * x6c::TK) == 0) ? 4 : 1; }
+
+}  // namespace
+
+extern "C" int pgasr_split_bf16_planes3(const float* src, int rows, int cols, int ld, int transpose,
+                                        unsigned short* hi, unsigned short* mid, unsigned short* lo, void* stream) {
+    if (!src || !hi || !mid || !lo || rows <= 0 || cols <= 0 || ld < cols) return PGASR_ERR_INVALID_ARG;
+    const size_t total = (size_t)rows * cols;
+    PGASR_LAUNCH_KERNEL(split_planes3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                        src, rows, cols, ld, transpose, hi, mid, lo);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
+
+static bool x6w_shape_ok(int M, int N, int K, const float* A, int lda, int ldc, const void* p0, const void* p1, const void* p2) {
+    if ((K % x6c::TK) || K < 4 * x6c::TK || (N % x6c::TN) || (lda & 3)) return false;
+    if ((((size_t)A) & 15) || (((size_t)p0) & 15) || (((size_t)p1) & 15) || (((size_t)p2) & 15)) return false;
+    if ((size_t)M * ldc * 4 >= ((size_t)1 << 32) || (size_t)M * lda * 4 >= ((size_t)1 << 32)) return false;   // buffer / 32-bit-offset addressing
+    return (M + x6c::TM - 1) / x6c::TM <= 65535;
+}
+
+extern "C" int pgasr_gemm_x6w_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
+                                  const unsigned short* Wmid, const unsigned short* Wlo, float* C, int ldc,
+                                  const float* bias, const float* dact_y, float slope, void* stream) {
+    if (!A || !Whi || !Wmid || !Wlo || !C || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N) return PGASR_ERR_INVALID_ARG;
+    if (!x6w_shape_ok(M, N, K, A, lda, ldc, Whi, Wmid, Wlo)) return PGASR_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)x6c::LDS_BYTES;
+    if (hipFuncSetAttribute((const void*)x6c::gemm_x6c_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PGASR_ERR_LAUNCH;
+    DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, dact_y, slope, nullptr, nullptr, nullptr, 0, 0, 0, 1, 0, nullptr, nullptr, 0, Wmid};
+    PGASR_LAUNCH_KERNEL(x6c::gemm_x6c_kernel<false>, dim3((unsigned)(N / x6c::TN), (unsigned)((M + x6c::TM - 1) / x6c::TM)), dim3(x6c::THREADS), lds,
+                        (hipStream_t)stream, g);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
+
+extern "C" size_t pgasr_gemm_x6w_feed_workspace_bytes(void) { return 1024 + (size_t)X6_FEED_SPLIT_MAX * 4 * x6c::SLAB_FLOATS * 4; }
+
+// Column tiles per direction half that a six-product feed of an N-column product counts in tiles_done (the consumer's fed_need)
+extern "C" int pgasr_gemm_x6w_feed_col_tiles(int N) { return (N > 0 && N % (2 * x6c::TN) == 0) ? N / (2 * x6c::TN) : 0; }
+
+extern "C" int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
+                                       const unsigned short* Wmid, const unsigned short* Wlo, float* C, int ldc, const float* bias,
+                                       const unsigned* xcc_busy, unsigned* tiles_done, int order,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !Whi || !Wmid || !Wlo || !C || !tiles_done || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N) return PGASR_ERR_INVALID_ARG;
+    if (order < 0 || order > 1) return PGASR_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < 1024) return PGASR_ERR_WORKSPACE;
+    if (!x6w_shape_ok(M, N, K, A, lda, ldc, Whi, Wmid, Wlo) || pgasr_gemm_x6w_feed_col_tiles(N) == 0) return PGASR_ERR_UNSUPPORTED;
+    if ((size_t)M * ldc * 4 >= ((size_t)1 << 31)) return PGASR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int mt = (M + x6c::TM - 1) / x6c::TM, nt = N / x6c::TN;
+    const size_t lds = (size_t)x6c::LDS_BYTES + 16;
+    if (hipFuncSetAttribute((const void*)x6c::gemm_x6c_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PGASR_ERR_LAUNCH;
+    if (hipMemsetAsync(workspace, 0, 1024, st) != hipSuccess) return PGASR_ERR_LAUNCH;     // tile counter + arrival counters
+    // the first tile groups (16 time-ordered groups, at most X6_FEED_SPLIT_MAX tiles and what the workspace holds) are split into
+    // K-quarters: the sweep is waiting for exactly these
+    const int quarters = x6_quarters(K);
+    int split = 0;
+    if (quarters == 4) {
+        const size_t room = (workspace_bytes - 1024) / ((size_t)4 * x6c::SLAB_FLOATS * 4);
+        split = 16 * nt;
+        if (split > X6_FEED_SPLIT_MAX) split = X6_FEED_SPLIT_MAX;
+        if ((size_t)split > room) split = (int)room;
+        if (split > mt * nt) split = mt * nt;
+    }
+    DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, nullptr, 0.f, (unsigned*)workspace, xcc_busy, tiles_done, mt, nt, order,
+                  quarters, split, (float*)((char*)workspace + 1024), (unsigned*)workspace + 64, 0, Wmid};
+    for (int pass = 0; pass < 2; ++pass) {     // one persistent workgroup per CU; pass 1 ignores the busy counters
+        if (pass == 1) g.xcc_busy = nullptr;
+        PGASR_LAUNCH_KERNEL(x6c::gemm_x6c_kernel<true>, dim3(256), dim3(x6c::THREADS), lds, st, g);
+        PGASR_CHECK_LAUNCH();
+    }
+    return PGASR_OK;
+}
+
+// ---- internal: the six-product TN kernel behind pgasr_lstm_wgrads_streamed(planes = 3) (same contract as pgasr_internal_tn256_launch) ----
+int pgasr_internal_tn6_launch(PgasrTn256Args a, int masked_then_unmasked, hipStream_t st, const PgasrTn256Args* second) {
+    PgasrTn256Args b{};
+    if (!pgasr_internal_tn256_ok(a)) return PGASR_ERR_UNSUPPORTED;
+    if (second) {
+        if (!a.queue || second->splitk != a.splitk || !pgasr_internal_tn256_ok(*second)) return PGASR_ERR_UNSUPPORTED;
+        b = *second;
+    }
+    const size_t lds = (size_t)t6::LDS_BYTES;
+    if (hipFuncSetAttribute((const void*)t6::gemm_t6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PGASR_ERR_LAUNCH;
+    const unsigned nitems = (unsigned)((a.N / t6::TN) * (a.M / t6::TM)) * (unsigned)(a.batch * a.splitk);
+    if (!a.queue) {
+        PGASR_LAUNCH_KERNEL(t6::gemm_t6_kernel<false>, dim3(nitems), dim3(t6::THREADS), lds, st, a, b);
+        PGASR_CHECK_LAUNCH();
+        return PGASR_OK;
+    }
+    if (a.gate && hipFuncSetAttribute((const void*)t6::gemm_t6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PGASR_ERR_LAUNCH;
+    const unsigned* busy = a.xcc_busy;
+    for (int pass = 0; pass < ((masked_then_unmasked && busy) ? 2 : 1); ++pass) {
+        a.xcc_busy = (pass == 0) ? busy : nullptr;
+        b.xcc_busy = a.xcc_busy;
+        if (a.gate) PGASR_LAUNCH_KERNEL(t6::gemm_t6_kernel<true>, dim3(256), dim3(t6::THREADS), lds, st, a, b);
+        else        PGASR_LAUNCH_KERNEL(t6::gemm_t6_kernel<false>, dim3(256), dim3(t6::THREADS), lds, st, a, b);
+        PGASR_CHECK_LAUNCH();
+    }
+    return PGASR_OK;
+}

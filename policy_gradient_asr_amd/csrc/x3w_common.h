@@ -26,6 +26,7 @@ struct DmaGemmArgs {
     float* slabs;               // FEED: [split_tiles][4][64][512] partial accumulators
     unsigned* arrive;           // FEED: [split_tiles] quarters finished (zeroed by the host)
     int single;                 // FEED: every workgroup takes ONE work item and leaves (the head launch in front of a sweep)
+    const unsigned short* Wmid; // six-product kernels (gemm_x6.hip): the middle plane of the 3-plane split (hi, mid, lo)
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_base) {
@@ -41,6 +42,18 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi_pk, unsi
     const float h0 = __uint_as_float(hi_pk << 16), h1 = __uint_as_float(hi_pk & 0xFFFF0000u);
     const bf2 l = __builtin_convertvector((f2){x0 - h0, x1 - h1}, bf2);
     lo_pk = __builtin_bit_cast(unsigned, l);
+}
+
+// 3-plane split of a pair: plane p = bf16 of what the planes before it left over (every subtraction is exact in fp32), so
+// x = hi + mid + lo to 2^-24 relative -- the operand format of the fp32-faithful six-product kernels (gemm_x6.hip)
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& hi_pk, unsigned& mid_pk, unsigned& lo_pk) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    hi_pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){x0, x1}, bf2));
+    float r0 = x0 - __uint_as_float(hi_pk << 16), r1 = x1 - __uint_as_float(hi_pk & 0xFFFF0000u);
+    mid_pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){r0, r1}, bf2));
+    r0 -= __uint_as_float(mid_pk << 16); r1 -= __uint_as_float(mid_pk & 0xFFFF0000u);
+    lo_pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){r0, r1}, bf2));
 }
 
 // XCD-aware tile order (same remap as gemm.hip): each XCD walks a contiguous run of the

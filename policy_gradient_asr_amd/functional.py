@@ -322,6 +322,8 @@ class BLSTMLayerFn(torch.autograd.Function):
             torch.cuda.current_stream().wait_event(prepacked.ready)
         wih_perm, bias_perm, pack_f, pack_b = prepacked.wih_perm, prepacked.bias_perm, prepacked.pack_f, prepacked.pack_b
         ctx.planes_t = prepacked.planes_t
+        npl = len(prepacked.planes) if prepacked.planes is not None else hipops.LSTM_PLANES   # bf16 planes per fp32 operand: the arithmetic of this layer's big products
+        ctx.nplanes = npl
         ctx.fed_bwd = prepacked.fed_bwd       # zeroed counters for this layer's deferred input-gradient GEMM (or None)
         prepacked.fed_bwd = None
         ctx.slab_words = prepacked.slab       # zeroed publication words for this layer's streamed backward sweep (or None)
@@ -333,8 +335,9 @@ class BLSTMLayerFn(torch.autograd.Function):
         ctx.out_dropout = tuple(out_dropout) if out_dropout is not None else None
         out_drop = torch.empty_like(out) if out_dropout is not None else None
         dkw = {"out_drop": out_drop, "drop": ctx.out_dropout}
-        x3w = prepacked.planes is not None and hipops.gemm_x3w_ok(T * B, G, I)   # LDS-DMA kernel, pre-split weight planes
-        if x3w and FEED_AHEAD and hipops.lstm_fed_ok(T, B) and hipops.streams_concurrent(grad_overlap.second_side_stream()):
+        x3w = prepacked.planes is not None and hipops.gemm_x3w_ok(T * B, G, I, planes=npl)   # LDS-DMA kernel, pre-split weight planes
+        if (x3w and FEED_AHEAD and hipops.lstm_fed_ok(T, B) and hipops.x3w_feed_col_tiles(G, npl) > 0
+                and hipops.streams_concurrent(grad_overlap.second_side_stream())):
             # the projection leaves the critical path: the sweep is launched FIRST and its helper workgroups wait for
             # the row tiles a GEMM on the side stream produces, in consumption order, on the XCDs the sweep leaves free
             main = torch.cuda.current_stream()
@@ -348,11 +351,11 @@ class BLSTMLayerFn(torch.autograd.Function):
             # per workgroup, whole chip, ~30 us), so that the rows of the sweep's first steps are in memory when it starts;
             # without it a fed sweep sits ~50-70 us on its first rows (stream gate + launch + first tiles).  The rest of
             # the queue follows on the feed stream as before.
-            head = hipops.x3w_feed_head_items(G, I) > 0
+            head = hipops.x3w_feed_head_items(G, I, planes=npl) > 0
             ws_feed = hipops.gemm_x3w_feed(x, prepacked.planes, gates, T * B, G, I, bias_perm, 0, done, phase=1) if head else None
             zeroed = torch.cuda.Event()
             zeroed.record()
-            hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, fed=done, fed_need=hipops.x3w_feed_col_tiles(G), **dkw)
+            hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, fed=done, fed_need=hipops.x3w_feed_col_tiles(G, npl), **dkw)
             side.wait_event(zeroed)
             busy = hipops.lstm_busy_ptr(T, B, False, x.device)
             with torch.cuda.stream(side):
@@ -386,6 +389,7 @@ class BLSTMLayerFn(torch.autograd.Function):
         T, B, I = x.shape
         G = 2 * 4 * HID
         dev = x.device
+        npl = ctx.nplanes
         dout = dout.contiguous()
         rec = grad_overlap._deferred.pop(dout.data_ptr(), None) if grad_overlap.enabled else None
         if ctx.out_dropout is not None:
@@ -451,7 +455,8 @@ class BLSTMLayerFn(torch.autograd.Function):
                 grad_overlap.upper_grads_hook(swept)
         dx = None
         defer = (ctx.needs_input_grad[0] and grad_overlap.enabled and FEED_AHEAD and FEED_BWD and ctx.sweep_follows and not ctx.has_dact
-                 and ctx.planes_t is not None and hipops.gemm_x3w_ok(T * B, I, G) and I % 256 == 0 and I == 2 * HID
+                 and ctx.planes_t is not None and hipops.gemm_x3w_ok(T * B, I, G, planes=npl) and I % 256 == 0 and I == 2 * HID
+                 and hipops.x3w_feed_col_tiles(I, npl) > 0
                  and hipops.lstm_fed_ok(T, B) and hipops.streams_concurrent(grad_overlap.side_stream()))
         if defer:
             # another layer's backward sweep consumes dx (through at most a dropout): leave the product to that layer's
@@ -468,7 +473,7 @@ class BLSTMLayerFn(torch.autograd.Function):
 
             def head(dg=dg, dx=dx, done=done, planes_t=planes_t):
                 """On the consuming sweep's stream, in front of its launch: the first tile groups (see the forward path)."""
-                if hipops.x3w_feed_head_items(I, G) > 0:
+                if hipops.x3w_feed_head_items(I, G, planes=npl) > 0:
                     feed_ws.append(hipops.gemm_x3w_feed(dg, planes_t, dx, T * B, I, G, None, 0, done, order=1, phase=1))
                     return True
                 return False
@@ -479,18 +484,18 @@ class BLSTMLayerFn(torch.autograd.Function):
                 side_ = torch.cuda.current_stream()
                 for t_ in (dg, dx, done) + tuple(planes_t) + tuple(feed_ws):
                     streams.hold(t_, side_)
-            grad_overlap._deferred[dx.data_ptr()] = {"dx": dx, "done": done, "need": hipops.x3w_feed_col_tiles(I), "drop": None,
+            grad_overlap._deferred[dx.data_ptr()] = {"dx": dx, "done": done, "need": hipops.x3w_feed_col_tiles(I, npl), "drop": None,
                                                      "launch": launch, "head": head}
         elif ctx.needs_input_grad[0]:
             dx = torch.empty(T, B, I, dtype=torch.float32, device=dev)
-            if (ctx.sweep_follows and not ctx.has_dact and ctx.planes_t is not None and hipops.gemm_x3w_ok(T * B, I, G)
-                    and I == 2 * HID and hipops.x3w_feed_col_tiles(I) > 0 and T * B * I * 4 < 2 ** 31):
+            if (ctx.sweep_follows and not ctx.has_dact and ctx.planes_t is not None and hipops.gemm_x3w_ok(T * B, I, G, planes=npl)
+                    and I == 2 * HID and hipops.x3w_feed_col_tiles(I, npl) > 0 and T * B * I * 4 < 2 ** 31):
                 # the product that feed-ahead would have run beside the next sweep, in the sequential order: the SAME kernel
                 # with the same decomposition (its first tiles are fixed-order sums of K-quarters), no XCD mask, before the
                 # sweep -- so that both orders give the same bits
                 done = torch.zeros(2 * ((T * B + 255) // 256), dtype=torch.int32, device=dev)
                 hipops.gemm_x3w_feed(dg, ctx.planes_t, dx, T * B, I, G, None, 0, done, order=1)
-            elif ctx.planes_t is not None and hipops.gemm_x3w_ok(T * B, I, G):
+            elif ctx.planes_t is not None and hipops.gemm_x3w_ok(T * B, I, G, planes=npl):
                 hipops.gemm_x3w(dg, ctx.planes_t, dx, T * B, I, G,
                                 dact_y=dact_y if ctx.has_dact else None, slope=LEAKY_SLOPE)
             else:
@@ -504,7 +509,7 @@ class BLSTMLayerFn(torch.autograd.Function):
                 # both products in one launch, summed over the time slabs that the streamed order uses: the same bits
                 dwih = torch.empty(G, I, dtype=torch.float32, device=dev)
                 dwhh = torch.empty(2, 4 * HID, HID, dtype=torch.float32, device=dev)
-                hipops.lstm_wgrads(dg, x, out, T, B, I, dwih, dwhh, busy_ptr=hipops.GEMM_XCC_BUSY_PTR)
+                hipops.lstm_wgrads(dg, x, out, T, B, I, dwih, dwhh, busy_ptr=hipops.GEMM_XCC_BUSY_PTR, planes=npl)
                 dbias = torch.empty(G, dtype=torch.float32, device=dev)
                 hipops.colsum(dbias_part, dbias_part.shape[0], G, G, dbias)
                 if accumulate_into is not None:
@@ -568,7 +573,7 @@ class BLSTMLayerFn(torch.autograd.Function):
                 dwih = torch.empty(G, I, dtype=torch.float32, device=dev)
                 dwhh = torch.empty(2, 4 * HID, HID, dtype=torch.float32, device=dev)
                 hipops.lstm_wgrads(dg, x, out, T, B, I, dwih, dwhh, busy_ptr=busy if grad_overlap.confine else 0,
-                                   slab=slab, err_ws=sweep_ws)
+                                   slab=slab, err_ws=sweep_ws, planes=npl)
                 s3.wait_event(swept)             # the bias partial sums are written at the sweep's very end
                 dbias = torch.empty(G, dtype=torch.float32, device=dev)
                 hipops.colsum(dbias_part, dbias_part.shape[0], G, G, dbias)
@@ -608,11 +613,12 @@ def prepack_blstm(params, in_dim):
     params = [p.contiguous() for p in params]
     pk.wih_perm, pk.bias_perm, pk.pack_f, pk.pack_b = hipops.lstm_pack(params, in_dim)
     G = 2 * 4 * HID
-    # both GEMM roles of W_ih: N=G,K=in and N=in,K=G; the pre-split planes (and with them the LDS-DMA GEMM and the
-    # feed-ahead order) belong to the bf16x3 mode -- in "f32" mode the projections run on the exact fp32 MFMA kernel
-    ok = in_dim % 32 == 0 and in_dim % 128 == 0 and hipops.GEMM_PRECISION == 1
-    pk.planes = hipops.split_planes(pk.wih_perm) if ok else None                      # (G, in): forward projection
-    pk.planes_t = hipops.split_planes(pk.wih_perm, transpose=True) if ok else None    # (in, G): input gradient
+    # both GEMM roles of W_ih: N=G,K=in and N=in,K=G, pre-split into the bf16 planes of the precision mode: (hi, lo) for the
+    # bf16x3 kernels, (hi, mid, lo) for the six-product kernels of the "f32" mode (gemm_x6.hip: 256-wide tiles, 16-deep steps)
+    npl = hipops.LSTM_PLANES
+    ok = in_dim % 128 == 0 if npl == 2 else (in_dim % 256 == 0 and in_dim >= 64)
+    pk.planes = hipops.split_planes(pk.wih_perm, planes=npl) if ok else None                      # (G, in): forward projection
+    pk.planes_t = hipops.split_planes(pk.wih_perm, transpose=True, planes=npl) if ok else None    # (in, G): input gradient
     pk.ready = None
     pk.fed_fwd = pk.fed_bwd = pk.slab = None      # pre-zeroed tile counters / publication words of this step (prepack_blstm_layers)
     return pk

@@ -296,10 +296,11 @@ LSTM_PLANES = 2      # bf16 planes per fp32 operand in the recurrent sweeps: 2 =
 # The arithmetic of the whole path is a MODE of the host layer:
 #   "bf16x3": every dense product = 3 bf16 MFMA terms of a 2-plane split (~16 operand bits), fp32 accumulate; the input
 #             affine (whose sign feeds leaky_relu') on the exact fp32 MFMA.  Within north_star's 1e-3 bar; the fast path.
-#   "f32":    the reference's arithmetic (torch fp32: nn.Linear / nn.LSTM, model.py:38-44): every hoisted GEMM on the exact
-#             fp32 MFMA (v_mfma_f32_32x32x2_f32), the recurrent sweeps on the 3-plane split with six products (every term
-#             down to 2^-24).  No pre-split bf16 weight planes exist in this mode, so the LDS-DMA GEMM and the feed-ahead
-#             order (both bf16x3 kernels) are not used: projections run before their sweeps.
+#   "f32":    the reference's arithmetic (torch fp32: nn.Linear / nn.LSTM, model.py:38-44): every fp32 operand of a big product
+#             as THREE bf16 planes and the product as SIX MFMA terms (every term down to 2^-24) -- the recurrent sweeps
+#             (lstm.hip NP = 3) and, since round 4, the hoisted W_ih products and the weight gradients too (gemm_x6.hip), so the
+#             mode runs the same feed-ahead and streamed orders as "bf16x3"; the small products (input affine, CTC head) on
+#             the exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
 PRECISION_MODES = {"bf16x3": (1, 2), "f32": (0, 3)}
 _precision = "bf16x3"
 
@@ -361,41 +362,60 @@ def gemm(A, B, C, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=N
     return C
 
 
-def split_planes(w, transpose=False):
-    """fp32 matrix (rows, cols) -> bf16 (hi, lo) planes (int16 storage) of shape (rows, cols), or
-    (cols, rows) with ``transpose``: the pre-split weight operand of ``gemm_x3w``."""
+def split_planes(w, transpose=False, planes=None):
+    """fp32 matrix (rows, cols) -> bf16 planes (int16 storage) of shape (rows, cols), or (cols, rows) with ``transpose``: the
+    pre-split weight operand of ``gemm_x3w``.  planes = 2: (hi, lo), the bf16x3 kernels' operand; 3: (hi, mid, lo), the
+    six-product kernels' (precision mode "f32"); None: what the current precision mode uses."""
     lib = _lib.load()
     _req(w, torch.float32, "w")
     if w.dim() != 2 or w.stride(1) != 1:
         raise _lib.PgasrError("split_planes wants a row-major 2-D tensor")
+    planes = LSTM_PLANES if planes is None else int(planes)
+    if planes not in (2, 3):
+        raise _lib.PgasrError("split_planes: 2 or 3 planes")
     rows, cols = w.shape
     shape = (cols, rows) if transpose else (rows, cols)
-    hi = torch.empty(shape, dtype=torch.int16, device=w.device)
-    lo = torch.empty(shape, dtype=torch.int16, device=w.device)
-    st = lib.pgasr_split_bf16_planes(w.data_ptr(), rows, cols, w.stride(0), int(transpose), hi.data_ptr(), lo.data_ptr(), _stream())
+    out = tuple(torch.empty(shape, dtype=torch.int16, device=w.device) for _ in range(planes))
+    if planes == 3:
+        st = lib.pgasr_split_bf16_planes3(w.data_ptr(), rows, cols, w.stride(0), int(transpose), *[t.data_ptr() for t in out], _stream())
+    else:
+        st = lib.pgasr_split_bf16_planes(w.data_ptr(), rows, cols, w.stride(0), int(transpose), *[t.data_ptr() for t in out], _stream())
     _lib.check(st, "pgasr_split_bf16_planes")
-    return hi, lo
+    return out
 
 
-def gemm_x3w_ok(M, N, K, lda=None):
-    """Shapes the LDS-DMA kernel takes (else use ``gemm``)."""
+def gemm_x3w_ok(M, N, K, lda=None, planes=2):
+    """Shapes the LDS-DMA kernels take (else use ``gemm``): planes = 2 the bf16x3 kernels, 3 the six-product ones."""
     lda = K if lda is None else lda
+    if planes == 3:
+        return K % 16 == 0 and K >= 64 and N % 256 == 0 and lda % 4 == 0 and M > 0 and M * max(N, lda) * 4 < 2 ** 32
     return K % 32 == 0 and N % 128 == 0 and lda % 4 == 0 and M > 0
 
 
+def _check_planes(planes, N, K, what):
+    if len(planes) not in (2, 3):
+        raise _lib.PgasrError(f"{what}: planes must be a (hi, lo) or (hi, mid, lo) tuple")
+    for t in planes:
+        if tuple(t.shape) != (N, K) or t.dtype != torch.int16 or not t.is_contiguous() or not t.is_cuda:
+            raise _lib.PgasrError(f"{what} planes must be contiguous int16 (N, K) GPU tensors")
+
+
 def gemm_x3w(A, planes, C, M, N, K, lda=None, ldc=None, bias=None, dact_y=None, slope=0.01):
-    """C[M,N] = A[M,K] @ W[N,K]^T (+bias) (*leaky'(dact_y)); W given as ``split_planes`` output."""
+    """C[M,N] = A[M,K] @ W[N,K]^T (+bias) (*leaky'(dact_y)); W given as ``split_planes`` output: two planes -> the bf16x3
+    kernels (three products), three planes -> the fp32-faithful six-product kernel (gemm_x6.hip)."""
     lib = _lib.load()
-    hi, lo = planes
     for t, nm in ((A, "A"), (C, "C"), (bias, "bias"), (dact_y, "dact_y")):
         if t is not None and (not t.is_cuda or t.dtype != torch.float32):
             raise _lib.PgasrError(f"gemm_x3w operand {nm} must be a float32 GPU tensor")
-    if tuple(hi.shape) != (N, K) or tuple(lo.shape) != (N, K) or hi.dtype != torch.int16 or not hi.is_contiguous() or not lo.is_contiguous():
-        raise _lib.PgasrError("gemm_x3w planes must be contiguous int16 (N, K)")
+    _check_planes(planes, N, K, "gemm_x3w")
     with _timed("gemm_f32"):
-        st = lib.pgasr_gemm_x3w_f32(M, N, K, A.data_ptr(), K if lda is None else lda, hi.data_ptr(), lo.data_ptr(),
-                                    C.data_ptr(), N if ldc is None else ldc, _p(bias), _p(dact_y), float(slope), _stream())
-    _lib.check(st, "pgasr_gemm_x3w_f32")
+        if len(planes) == 3:
+            st = lib.pgasr_gemm_x6w_f32(M, N, K, A.data_ptr(), K if lda is None else lda, *[t.data_ptr() for t in planes],
+                                        C.data_ptr(), N if ldc is None else ldc, _p(bias), _p(dact_y), float(slope), _stream())
+        else:
+            st = lib.pgasr_gemm_x3w_f32(M, N, K, A.data_ptr(), K if lda is None else lda, planes[0].data_ptr(), planes[1].data_ptr(),
+                                        C.data_ptr(), N if ldc is None else ldc, _p(bias), _p(dact_y), float(slope), _stream())
+    _lib.check(st, "pgasr_gemm_x6w_f32" if len(planes) == 3 else "pgasr_gemm_x3w_f32")
     return C
 
 
@@ -506,10 +526,11 @@ def lstm_fed_ok(T, B):
     return bool(_lib.load().pgasr_lstm_fed_ok(T, B, LSTM_FLAGS))
 
 
-def x3w_feed_col_tiles(N):
+def x3w_feed_col_tiles(N, planes=2):
     """Column tiles per direction half that ``gemm_x3w_feed`` counts per row tile for an N-column product: the
-    ``fed_need`` of the sweep it feeds (0: not a feedable width)."""
-    return int(_lib.load().pgasr_gemm_x3w_feed_col_tiles(int(N)))
+    ``fed_need`` of the sweep it feeds (0: not a feedable width).  planes: of the W operand (2 / 3, see ``gemm_x3w``)."""
+    lib = _lib.load()
+    return int(lib.pgasr_gemm_x6w_feed_col_tiles(int(N)) if planes == 3 else lib.pgasr_gemm_x3w_feed_col_tiles(int(N)))
 
 
 # Tile groups of a feeding GEMM computed IN FRONT of the fed sweep, on its own stream (pgasr_gemm_x3w_feed_f32 phase 1).
@@ -519,9 +540,11 @@ def x3w_feed_col_tiles(N):
 FEED_HEAD_GROUPS = int(_os_environ_get("PGASR_FEED_HEAD", "0"))
 
 
-def x3w_feed_head_items(N, K, groups=None):
-    """Work items of a feed's HEAD launch (0: this shape / tile structure has none)."""
+def x3w_feed_head_items(N, K, groups=None, planes=2):
+    """Work items of a feed's HEAD launch (0: this shape / tile structure has none; the six-product feeds have none)."""
     groups = FEED_HEAD_GROUPS if groups is None else groups
+    if planes == 3:
+        return 0
     return int(_lib.load().pgasr_gemm_x3w_feed_head_items(int(N), int(K), int(groups))) if groups > 0 else 0
 
 
@@ -530,17 +553,24 @@ def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done, order=0, ph
     phase 1 (head, on the sweep's stream in front of the sweep) returns the workspace that the phase-2 call (rest, on
     the feeding stream) must be given as ``ws``: both work on one queue."""
     lib = _lib.load()
-    hi, lo = planes
     for t, nm in ((A, "A"), (C, "C"), (bias, "bias")):
         if t is not None and (not t.is_cuda or t.dtype != torch.float32):
             raise _lib.PgasrError(f"gemm_x3w_feed operand {nm} must be a float32 GPU tensor")
-    if tuple(hi.shape) != (N, K) or tuple(lo.shape) != (N, K) or hi.dtype != torch.int16 or not hi.is_contiguous() or not lo.is_contiguous():
-        raise _lib.PgasrError("gemm_x3w_feed planes must be contiguous int16 (N, K)")
+    _check_planes(planes, N, K, "gemm_x3w_feed")
     if tiles_done.dtype != torch.int32 or tiles_done.numel() < 2 * ((M + 255) // 256):
         raise _lib.PgasrError("gemm_x3w_feed: tiles_done must hold 2 * ceil(M/256) int32 words")
+    if len(planes) == 3:
+        if phase != 0:
+            raise _lib.PgasrError("gemm_x3w_feed: the six-product feeds have no head launch")
+        if ws is None:
+            ws = _workspace(lib.pgasr_gemm_x6w_feed_workspace_bytes(), C.device, "x6w_feed")
+        st = lib.pgasr_gemm_x6w_feed_f32(M, N, K, A.data_ptr(), K, *[t.data_ptr() for t in planes], C.data_ptr(), N, _p(bias),
+                                         busy_ptr, tiles_done.data_ptr(), int(order), _p(ws), ws.numel(), _stream())
+        _lib.check(st, "pgasr_gemm_x6w_feed_f32")
+        return C
     if ws is None:
         ws = _workspace(lib.pgasr_gemm_x3w_feed_workspace_bytes(), C.device, "x3w_feed")
-    st = lib.pgasr_gemm_x3w_feed_f32(M, N, K, A.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), C.data_ptr(), N, _p(bias),
+    st = lib.pgasr_gemm_x3w_feed_f32(M, N, K, A.data_ptr(), K, planes[0].data_ptr(), planes[1].data_ptr(), C.data_ptr(), N, _p(bias),
                                      busy_ptr, tiles_done.data_ptr(), int(order), int(phase), FEED_HEAD_GROUPS if phase else 0,
                                      _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_gemm_x3w_feed_f32")
@@ -590,15 +620,18 @@ def lstm_wgrad_slabs(T):
 
 
 def lstm_wgrads_ok(T, B, in_dim):
-    """Shapes ``lstm_wgrads`` takes (the 256 x 256 TN kernel: both products in one launch)."""
-    return GEMM_PRECISION == 1 and T >= 2 and in_dim % 256 == 0 and B % 32 == 0 and T * B * 2048 * 4 < 2 ** 31
+    """Shapes ``lstm_wgrads`` takes (the 256 x 256 TN kernels: both products in one launch) -- in either precision mode:
+    bf16x3 runs gemm_c256.hip's kernel, f32 the six-product one of gemm_x6.hip."""
+    return T >= 2 and in_dim % 256 == 0 and B % 32 == 0 and T * B * 2048 * 4 < 2 ** 31
 
 
-def lstm_wgrads(dgates, x, out, T, B, in_dim, dwih, dwhh, busy_ptr=0, slab=None, err_ws=None):
+def lstm_wgrads(dgates, x, out, T, B, in_dim, dwih, dwhh, busy_ptr=0, slab=None, err_ws=None, planes=None):
     """dwih (2*4H, in_dim) = dgates^T x and dwhh (2, 4H, H) = dgates[d]^T h_prev(d) in one launch, summed over the time slabs
     of ``lstm_wgrad_slabs(T)``.  slab: the slab_done words of the STREAMED sweep that is still writing ``dgates`` on another
-    stream; err_ws: that sweep's workspace (its error word is set if a wait gives up)."""
+    stream; err_ws: that sweep's workspace (its error word is set if a wait gives up).
+    planes: 2 = bf16x3 products, 3 = the fp32-faithful six-product arithmetic; None = the current precision mode's."""
     lib = _lib.load()
+    planes = LSTM_PLANES if planes is None else int(planes)
     for t_, nm in ((dgates, "dgates"), (x, "x"), (out, "out"), (dwih, "dwih"), (dwhh, "dwhh")):
         _req(t_, torch.float32, nm)
     nbytes = lib.pgasr_lstm_wgrads_workspace_bytes(T, in_dim)
@@ -611,7 +644,7 @@ def lstm_wgrads(dgates, x, out, T, B, in_dim, dwih, dwhh, busy_ptr=0, slab=None,
         err_ptr = err_ws.data_ptr() + off.value
     with _timed("gemm_f32"):
         st = lib.pgasr_lstm_wgrads_streamed(_p(dgates), _p(x), _p(out), T, B, in_dim, _p(dwih), _p(dwhh), int(busy_ptr),
-                                            _p(slab), err_ptr, _p(ws), ws.numel(), _stream())
+                                            _p(slab), err_ptr, planes, _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_lstm_wgrads_streamed")
 
 

@@ -82,6 +82,51 @@ def test_gemm_x3w_lds_dma(M, N, K, with_bias, with_dact, tile, monkeypatch):
     assert hipops.gemm_x3w_ok(M, N, K) and not hipops.gemm_x3w_ok(M, N + 1, K) and not hipops.gemm_x3w_ok(M, N, K + 8)
 
 
+@pytest.mark.parametrize("M,N,K,with_bias,with_dact", [
+    (300, 256, 64, True, True),         # four 16-deep steps: the prologue alone fills the ring; ragged M inside one row tile
+    (777, 768, 80, True, False),        # five steps (3-unrolled loop ends mid-turn); ragged last row tile; three column tiles
+    (513, 256, 112, False, True),       # seven steps
+    (2000, 2048, 512, False, True),     # the input projection's K and N
+    (4096, 512, 2048, False, False),    # dX shape of the path (K = 8H): 128 steps
+    (1031, 512, 352, True, True),       # 22 steps
+])
+def test_gemm_x6w_six_product(M, N, K, with_bias, with_dact):
+    """pgasr_gemm_x6w_f32 (gemm_x6.hip: three bf16 planes per operand, six MFMA products, 16-deep steps) against fp64 at
+    fp32-GEMM accuracy -- the arithmetic of the "f32" precision mode -- and the exactness of the 3-plane split."""
+    from policy_gradient_asr_amd import hipops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.1
+    bias = torch.randn(N, generator=g) if with_bias else None
+    y = torch.randn(M, N, generator=g) if with_dact else None
+    want = A.double() @ W.double().t()
+    if with_bias:
+        want = want + bias.double()
+    if with_dact:
+        want = want * torch.where(y > 0, 1.0, 0.01).double()
+    planes = hipops.split_planes(W.to(DEV), planes=3)
+    assert len(planes) == 3
+    parts = [(p_.cpu().to(torch.int32) << 16).view(torch.float32).double() for p_ in planes]
+    assert float(((parts[0] + parts[1] + parts[2]) - W.double()).abs().max() / W.abs().max()) < 2.0 ** -23     # x = hi + mid + lo
+    two = hipops.split_planes(W.to(DEV), planes=2)
+    assert torch.equal(two[0], planes[0])                       # the hi plane is the same rounding in both splits
+    C = torch.full((M, N), float("nan"), device=DEV)
+    hipops.gemm_x3w(A.to(DEV), planes, C, M, N, K, bias=None if bias is None else bias.to(DEV),
+                    dact_y=None if y is None else y.to(DEV), slope=0.01)
+    e6 = rel_err(C.cpu(), want)
+    # the fp32 MFMA kernel on the same product: the six-product result must be of the same quality
+    C0 = torch.empty(M, N, device=DEV)
+    hipops.gemm(A.to(DEV), W.to(DEV), C0, M, N, K, transB=True, bias=None if bias is None else bias.to(DEV), precision=0)
+    if with_dact:
+        C0 = C0 * torch.where(y.to(DEV) > 0, 1.0, 0.01)
+    e0 = rel_err(C0.cpu(), want)
+    print(f"[x6w] M={M} N={N} K={K}: six-product {e6:.2e}  fp32 MFMA {e0:.2e}")
+    assert e6 < 2e-6 and e6 < 4 * e0 + 2e-7
+    planes_t = hipops.split_planes(W.t().contiguous().to(DEV), transpose=True, planes=3)
+    assert all(torch.equal(a, b) for a, b in zip(planes_t, planes))
+    assert hipops.gemm_x3w_ok(M, N, K, planes=3) and not hipops.gemm_x3w_ok(M, N + 128, K, planes=3) and not hipops.gemm_x3w_ok(M, N, K + 8, planes=3)
+
+
 @pytest.mark.parametrize("busy_mask", [0x00, 0x0F, 0xA5, 0xFE, 0xFF])
 def test_gemm_queue_mode_is_placement_independent(busy_mask):
     """Queue mode (pgasr_gemm_f32 xcc_busy != NULL): whichever XCDs are declared busy -- none, half, all but
@@ -110,11 +155,13 @@ def test_gemm_queue_mode_is_placement_independent(busy_mask):
     (512, 256, 2016, 5, 2),          # two batches (dW_hh's two directions), a shorter last slab, 63 pairs
     (2048, 512, 8000, 8, 1),         # eight row tiles x two column tiles x eight slabs = 128 items
 ])
-def test_gemm_tn_256_tile_weight_gradient_shapes(M, N, K, splitk, batch, monkeypatch):
+@pytest.mark.parametrize("precision,tol", [(1, 1e-5), (2, 1.5e-6)])
+def test_gemm_tn_256_tile_weight_gradient_shapes(M, N, K, splitk, batch, precision, tol, monkeypatch):
     """TN products with both operands k-major (dW = dY^T X, model.py:39-44 backward) on the 256 x 256 LDS-DMA tile of
     gemm_dma.hip (taken by pgasr_gemm_f32 for M, N % 256 == 0, K % 32 == 0, split-K slabs of multiples of 32): against
     fp64, with the reduce epilogue (accumulate into C), with batch strides, plain and in queue mode under every kind of
-    XCD mask -- bit-identical whichever workgroup computes which item."""
+    XCD mask -- bit-identical whichever workgroup computes which item.  precision 2: the same shapes on the six-product kernel
+    of gemm_x6.hip (three planes per operand, 16-deep steps) at fp32-GEMM accuracy."""
     from policy_gradient_asr_amd import hipops
     monkeypatch.setenv("PGASR_TN_TILE", "256")          # opt-in kernel (read by the library at every call)
     g = torch.Generator().manual_seed(M + N + K)
@@ -126,19 +173,22 @@ def test_gemm_tn_256_tile_weight_gradient_shapes(M, N, K, splitk, batch, monkeyp
     for mask in (None, 0x00, 0x0F, 0xFE, 0xFF):
         busy = None if mask is None else torch.tensor([(mask >> i) & 1 for i in range(8)], dtype=torch.int32, device=DEV)
         got = base.clone()
-        hipops.gemm(A, B, got, M, N, K, transA=True, splitk=splitk, accumulate=True, precision=1, batch=batch,
+        hipops.gemm(A, B, got, M, N, K, transA=True, splitk=splitk, accumulate=True, precision=precision, batch=batch,
                     strideA=K * M, strideB=K * N, strideC=M * N, xcc_busy=None if busy is None else busy.data_ptr())
         torch.cuda.synchronize()
         outs.append(got)
-    assert rel_err(outs[0].cpu(), ref) < 1e-5
+    assert rel_err(outs[0].cpu(), ref) < tol
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
     # sum_batches: the two batches' slabs summed into ONE output
     if batch > 1:
         one = torch.zeros(M, N, device=DEV)
-        hipops.gemm(A, B, one, M, N, K, transA=True, splitk=splitk, precision=1, batch=batch, sum_batches=True,
+        hipops.gemm(A, B, one, M, N, K, transA=True, splitk=splitk, precision=precision, batch=batch, sum_batches=True,
                     strideA=K * M, strideB=K * N, strideC=0)
-        assert rel_err(one.cpu(), (ref - base.double().cpu()).sum(0)) < 1e-5
+        assert rel_err(one.cpu(), (ref - base.double().cpu()).sum(0)) < tol
+    if precision == 2:          # shapes the TN kernel does not take have no six-product form: the call says so
+        with pytest.raises(Exception):
+            hipops.gemm(A, B, torch.empty(M, N, device=DEV), M, N + 4, K, transA=True, splitk=splitk, precision=2)
 
 
 def test_instnorm_affine_fwd_bwd():
@@ -292,10 +342,12 @@ def test_blstm_write_through_protocol_matches_default():
     (61, 20, [61] * 7 + list(range(60, 47, -1))),   # steps straddle row tiles, ragged last tile, second group of 4
     (1, 3, [1] * 3), (9, 16, [9] * 16),
 ])
-def test_blstm_fed_by_concurrent_projection_matches_sequential(T, B, lens):
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_blstm_fed_by_concurrent_projection_matches_sequential(T, B, lens, mode):
     """The forward sweep fed by a projection GEMM that runs beside it (functional.FEED_AHEAD: sweep launched first,
     helper workgroups wait per row tile) gives bit-identical outputs, saved activations and gradients to the
-    projection-then-sweep order; B > 32 falls back to the sequential order by itself."""
+    projection-then-sweep order; B > 32 falls back to the sequential order by itself.  mode "f32": the same with the
+    six-product feed kernel (gemm_x6.hip) and the 3-plane sweeps."""
     from policy_gradient_asr_amd import functional as Fh, hipops
     assert hipops.lstm_fed_ok(T, B) and not hipops.lstm_fed_ok(T, 33)
     if not hipops.streams_concurrent(Fh.grad_overlap.second_side_stream()):
@@ -310,8 +362,9 @@ def test_blstm_fed_by_concurrent_projection_matches_sequential(T, B, lens):
             Fh.FEED_AHEAD = feed
             params = [getattr(lstm, n).detach().to(DEV).requires_grad_(True) for n in names]
             xg = x.to(DEV).requires_grad_(True)
-            y = Fh.blstm_layer(xg, lengths.to(torch.int32).to(DEV), params)
-            y.backward(dy.to(DEV))
+            with hipops.precision(mode):
+                y = Fh.blstm_layer(xg, lengths.to(torch.int32).to(DEV), params)
+                y.backward(dy.to(DEV))
             torch.cuda.synchronize()
             hipops.lstm_check_error(hipops._lstm_ws(T, B, False, xg.device), B, False)
             res.append([y.detach().cpu(), xg.grad.cpu()] + [p.grad.cpu() for p in params])
@@ -331,13 +384,21 @@ def test_blstm_fed_by_concurrent_projection_matches_sequential(T, B, lens):
     (997, 32, [997] * 5 + list(range(996, 969, -1)), 0),    # a length that no slab size divides (configs[4]'s ragged batches)
     (200, 32, [200] * 32, 1),                               # write-through protocol: the storer waves release their own stores
 ])
-def test_streamed_backward_sweep_feeds_its_own_weight_gradients(T, B, lens, flags):
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 2e-5), ("f32", 2e-6)])
+def test_streamed_backward_sweep_feeds_its_own_weight_gradients(T, B, lens, flags, mode, tol):
     """pgasr_lstm_layer_bwd_streamed + pgasr_lstm_wgrads_streamed: the weight-gradient products of a layer run BESIDE the backward
     sweep that is still writing their dgates operand (flusher workgroup: L2 write-back per time slab, slab_done words; gated TN
     kernel: waits per slab, agent-scope loads).  Bit-identical to the sequential order (sweep, then the same launch un-gated), and
-    equal to the fp64 product of the same dgates to bf16x3 accuracy."""
+    equal to the fp64 product of the same dgates to bf16x3 accuracy -- mode "f32": to fp32-GEMM accuracy, on the six-product
+    gated kernel (gemm_x6.hip) behind a 3-plane sweep."""
     from policy_gradient_asr_amd import functional as Fh, hipops, streams
     dev = torch.device(DEV)
+    with hipops.precision(mode):
+        _streamed_case(T, B, lens, flags, tol, dev)
+
+
+def _streamed_case(T, B, lens, flags, tol, dev):
+    from policy_gradient_asr_amd import functional as Fh, hipops, streams
     side = streams.side_stream("test_streamed")
     if not hipops.streams_concurrent(side):
         pytest.skip("kernels of different streams are serialised here (profiler / launch-blocking)")
@@ -367,10 +428,10 @@ def test_streamed_backward_sweep_feeds_its_own_weight_gradients(T, B, lens, flag
         hipops.lstm_wgrads(dg_ref, xd, out, T, B, 512, dwih_ref, dwhh_ref)
         d64, x64, o64 = dg_ref.double().cpu(), xd.double().cpu(), out.double().cpu()
         want_ih = d64.reshape(T * B, G).t() @ x64.reshape(T * B, 512)
-        assert rel_err(dwih_ref.cpu(), want_ih) < 2e-5
+        assert rel_err(dwih_ref.cpu(), want_ih) < tol
         want_hh0 = d64[1:, :, :4 * H].reshape(-1, 4 * H).t() @ o64[:-1, :, :H].reshape(-1, H)
         want_hh1 = d64[:-1, :, 4 * H:].reshape(-1, 4 * H).t() @ o64[1:, :, H:].reshape(-1, H)
-        assert rel_err(dwhh_ref[0].cpu(), want_hh0) < 2e-5 and rel_err(dwhh_ref[1].cpu(), want_hh1) < 2e-5
+        assert rel_err(dwhh_ref[0].cpu(), want_hh0) < tol and rel_err(dwhh_ref[1].cpu(), want_hh1) < tol
         import time
         for rep in range(3):
             dg = gates0.clone()
