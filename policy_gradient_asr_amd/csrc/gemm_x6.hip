@@ -60,6 +60,20 @@ __device__ __forceinline__ void wait_pairs(Planes2& a, Planes2& b) {
                    "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2])
                  :: "memory");
 }
+__device__ __forceinline__ void read_row(u32x4_t (&o)[3], unsigned p) {       // one 32-row tile: hi, mid, lo
+    asm volatile("ds_read_b128 %0, %3\n\t"
+                 "ds_read_b128 %1, %3 offset:8192\n\t"
+                 "ds_read_b128 %2, %3 offset:16384"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void wait_row(u32x4_t (&o)[3]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]) :: "memory");
+}
+__device__ __forceinline__ void wait_row_pair(u32x4_t (&a)[3], Planes2& b) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2])
+                 :: "memory");
+}
 // three 8-byte LDS stores (hi plane, mid = + 8 KB, lo = + 16 KB), hidden from hipcc like the reads
 __device__ __forceinline__ void write_planes3(unsigned addr, unsigned h0, unsigned h1, unsigned m0, unsigned m1, unsigned l0, unsigned l1) {
     typedef __attribute__((ext_vector_type(2))) unsigned u2;
@@ -89,7 +103,10 @@ __device__ __forceinline__ void mfma6(f32x16 (&acc)[2], const u32x4_t (&a)[3], c
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[PA[p]]), __builtin_bit_cast(bf16x8_t, b[j][PB[p]]), acc[j], 0, 0, 0);
 }
 
-template <bool FEED>
+// VAR (PGASR_X6_VAR, read at every call; results identical): 0 = fragments of two row tiles read, waited for, multiplied
+// (gemm_c256.hip's structure); 1 = the fragments of row tile i + 1 are read while row tile i is multiplied (a wave's LDS latency
+// under its own MFMAs instead of its SIMD partner's); 2 = 1 with the A conversion in two halves behind different row tiles
+template <bool FEED, int VAR>
 __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];   // the ONLY LDS object
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -155,17 +172,15 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
         else load_a_one<1>(araw[decltype(setc)::value], aoff, kb, g.A);
     };
     auto load_a = [&](int kt, auto setc) { load_a1(kt, setc, 0); load_a1(kt, setc, 1); };
-    auto convert_a = [&](int buf, auto setc) {    // register set -> the three planes of buffer `buf`
+    auto convert_a1 = [&](int buf, auto setc, int j) {    // one of a register set's two rows -> the three planes of buffer `buf`
         constexpr int S = decltype(setc)::value;
         const unsigned base = lds0 + (unsigned)buf * ABUF_BYTES;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            unsigned h0, m0_, l0, h1, m1_, l1;
-            split3(__uint_as_float(araw[S][j].x), __uint_as_float(araw[S][j].y), h0, m0_, l0);
-            split3(__uint_as_float(araw[S][j].z), __uint_as_float(araw[S][j].w), h1, m1_, l1);
-            write_planes3(base + apw[j], h0, h1, m0_, m1_, l0, l1);
-        }
+        unsigned h0, m0_, l0, h1, m1_, l1;
+        split3(__uint_as_float(araw[S][j].x), __uint_as_float(araw[S][j].y), h0, m0_, l0);
+        split3(__uint_as_float(araw[S][j].z), __uint_as_float(araw[S][j].w), h1, m1_, l1);
+        write_planes3(base + apw[j], h0, h1, m0_, m1_, l0, l1);
     };
+    auto convert_a = [&](int buf, auto setc) { convert_a1(buf, setc, 0); convert_a1(buf, setc, 1); };
 
     // ---- fragment read offsets (hi plane; mid / lo = + 8 KB / + 16 KB) ----
     const int fr = lane & 31, fh = lane >> 5;
@@ -232,7 +247,51 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
         auto mem_a = [&](int s) { load_a1(kt + 1 + NA, setc, s); };
         Planes2 fb;
         __builtin_amdgcn_sched_barrier(0);
-        if (w < 4) {
+        if constexpr (VAR >= 1) {
+            // row tile i + 1's fragments are read while row tile i is multiplied; waves 0-3 (EARLY) convert before row 0 (VAR 2: half
+            // of it behind row 0), waves 4-7 behind row 1 (VAR 2: and row 2) -- the two waves of a SIMD never convert together
+            auto body = [&](auto earlyc) {
+                constexpr bool EARLY = decltype(earlyc)::value;
+                const unsigned ab = lds0 + (unsigned)cur * ABUF_BYTES, wb = lds0 + (unsigned)wst * WSTAGE_BYTES;
+                u32x4_t f0[3], f1[3];
+                auto conv = [&](int part) {          // part 0 / 1: the conversion's first / second half (VAR 1: all of it in part 0)
+                    if (part == 0) {
+                        wait_a_regs<EARLY ? 10 : 13>(araw[decltype(setc)::value]);
+                        convert_a1(cur ^ 1, setc, 0);
+                        if (VAR == 1) convert_a1(cur ^ 1, setc, 1);
+                    } else if (VAR == 2) convert_a1(cur ^ 1, setc, 1);
+                };
+                if (EARLY) { conv(0); __builtin_amdgcn_sched_barrier(0); }
+                read_pair(fb, wb + offB[0], wb + offB[1]);
+                read_row(f0, ab + offA[0]);
+                wait_row_pair(f0, fb);
+                read_row(f1, ab + offA[1]);
+                mfma6(acc[0], f0, fb);
+                __builtin_amdgcn_sched_barrier(0);
+                mem_w(0);
+                if (EARLY) conv(1);
+                __builtin_amdgcn_sched_barrier(0);
+                wait_row(f1);
+                read_row(f0, ab + offA[2]);
+                mfma6(acc[1], f1, fb);
+                __builtin_amdgcn_sched_barrier(0);
+                mem_w(1);
+                if (!EARLY) conv(0);
+                __builtin_amdgcn_sched_barrier(0);
+                wait_row(f0);
+                read_row(f1, ab + offA[3]);
+                mfma6(acc[2], f0, fb);
+                __builtin_amdgcn_sched_barrier(0);
+                mem_a(0);
+                if (!EARLY) conv(1);
+                __builtin_amdgcn_sched_barrier(0);
+                wait_row(f1);
+                mfma6(acc[3], f1, fb);
+                __builtin_amdgcn_sched_barrier(0);
+                mem_a(1);
+            };
+            if (w < 4) body(std::true_type{}); else body(std::false_type{});
+        } else if (w < 4) {
             wait_a_regs<10>(araw[decltype(setc)::value]);
             convert_a(cur ^ 1, setc);
             __builtin_amdgcn_sched_barrier(0);
@@ -589,6 +648,10 @@ __global__ __launch_bounds__(256) void split_planes3_kernel(const float* __restr
     lo[idx] = (unsigned short)l;
 }
 
+static int x6_var() {       // PGASR_X6_VAR (read at every call: A/B inside one process); default: see the kernel's header
+    const char* e = getenv("PGASR_X6_VAR");
+    return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0;
+}
 constexpr int X6_FEED_SPLIT_MAX = 32;      // split tiles per feed: 4 x 32 slabs of 256 KB = 32 MB of workspace
 int x6_quarters(int K) { return (K >= 1024 && K % (4 * x6c::TK) == 0) ? 4 : 1; }
 
@@ -617,10 +680,12 @@ extern "C" int pgasr_gemm_x6w_f32(int M, int N, int K, const float* A, int lda, 
     if (!A || !Whi || !Wmid || !Wlo || !C || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N) return PGASR_ERR_INVALID_ARG;
     if (!x6w_shape_ok(M, N, K, A, lda, ldc, Whi, Wmid, Wlo)) return PGASR_ERR_UNSUPPORTED;
     const size_t lds = (size_t)x6c::LDS_BYTES;
-    if (hipFuncSetAttribute((const void*)x6c::gemm_x6c_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    const int var = x6_var();
+    auto kern = var == 2 ? x6c::gemm_x6c_kernel<false, 2> : var == 1 ? x6c::gemm_x6c_kernel<false, 1> : x6c::gemm_x6c_kernel<false, 0>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
     DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, dact_y, slope, nullptr, nullptr, nullptr, 0, 0, 0, 1, 0, nullptr, nullptr, 0, Wmid};
-    PGASR_LAUNCH_KERNEL(x6c::gemm_x6c_kernel<false>, dim3((unsigned)(N / x6c::TN), (unsigned)((M + x6c::TM - 1) / x6c::TM)), dim3(x6c::THREADS), lds,
+    PGASR_LAUNCH_KERNEL(kern, dim3((unsigned)(N / x6c::TN), (unsigned)((M + x6c::TM - 1) / x6c::TM)), dim3(x6c::THREADS), lds,
                         (hipStream_t)stream, g);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
@@ -643,7 +708,9 @@ extern "C" int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int 
     hipStream_t st = (hipStream_t)stream;
     const int mt = (M + x6c::TM - 1) / x6c::TM, nt = N / x6c::TN;
     const size_t lds = (size_t)x6c::LDS_BYTES + 16;
-    if (hipFuncSetAttribute((const void*)x6c::gemm_x6c_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    const int var = x6_var();
+    auto kern = var == 2 ? x6c::gemm_x6c_kernel<true, 2> : var == 1 ? x6c::gemm_x6c_kernel<true, 1> : x6c::gemm_x6c_kernel<true, 0>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
     if (hipMemsetAsync(workspace, 0, 1024, st) != hipSuccess) return PGASR_ERR_LAUNCH;     // tile counter + arrival counters
     // the first tile groups (16 time-ordered groups, at most X6_FEED_SPLIT_MAX tiles and what the workspace holds) are split into
@@ -661,7 +728,7 @@ extern "C" int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int 
                   quarters, split, (float*)((char*)workspace + 1024), (unsigned*)workspace + 64, 0, Wmid};
     for (int pass = 0; pass < 2; ++pass) {     // one persistent workgroup per CU; pass 1 ignores the busy counters
         if (pass == 1) g.xcc_busy = nullptr;
-        PGASR_LAUNCH_KERNEL(x6c::gemm_x6c_kernel<true>, dim3(256), dim3(x6c::THREADS), lds, st, g);
+        PGASR_LAUNCH_KERNEL(kern, dim3(256), dim3(x6c::THREADS), lds, st, g);
         PGASR_CHECK_LAUNCH();
     }
     return PGASR_OK;

@@ -464,6 +464,9 @@ __device__ __forceinline__ void helper_loop(const LstmArgs& a, int cl, int dir, 
 // front of its polling loads -- the sweep ran 1.63 ms with that traffic in the compute waves and
 // 1.05 ms without it, while a cached load in the same place cost nothing.
 // ------------------------------------------------------------------------------------------
+#ifndef PGASR_FWD_XLAYOUT
+#define PGASR_FWD_XLAYOUT 1
+#endif
 constexpr int IO_WAVE = 4;        // first non-compute wave
 constexpr int LOADER_WAVE = 4, STORER_WAVE = 5;
 #ifndef PGASR_FWD_LEAD
@@ -493,7 +496,11 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_base) {
 // k-quarter [64w, 64w+64) of h_{t-1} into all 64 gate rows of the workgroup (4 MFMA tiles x 2
 // k-steps x 3 split terms); the four partial tiles are summed through LDS and each compute thread
 // finishes ONE (unit, utterance) cell.
-// exchange slot per cluster: [parity 2][kc 32][n 16][plane NP][8 bf16]; member g owns kc = 2g, 2g+1.
+// exchange slot per cluster: [parity 2][kc 32][plane NP][n 16][8 bf16]; member g owns kc = 2g, 2g+1.  (Rounds 1-3 had the plane
+// inside the utterance, [kc][n][plane][8]: a poll instruction -- 4 kc x 16 n x 16 B of ONE plane -- then touched every line of
+// 4 x 16 x NP x 16 B and used 1/NP of each, 64 line requests per wave and step with two planes, 144 with three; the exchange is
+// request-bound, and stamps put the three-plane poll at 1259 cycles against 760.  Plane-major, an instruction reads 8
+// full lines: 32 / 48 requests.  PGASR_FWD_XLAYOUT=0 builds the old layout for A/B.)
 // Measured and NOT kept (round 3, commit "second forward-sweep structure" in the history): the polled h_{t-1} itself through
 // LDS instead of the partial tiles -- every wave copies its validated k-quarter into an LDS image, one barrier, every wave
 // reads the whole 16 KB and multiplies all 256 k into its OWN 16 gate rows, so that the 16 x 16 MFMA output hands each lane
@@ -653,9 +660,15 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
                     POLL_FENCE();
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
+#if PGASR_FWD_XLAYOUT
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl)
+                            vp[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, pbase + (unsigned)(((((4 * (2 * w + i) + q) * NP + pl) * 16 + n)) * 16), 0, 16);
+#else
                         const unsigned off = pbase + (unsigned)((((4 * (2 * w + i) + q) * 16 + n) * NP) * 16);
 #pragma unroll
                         for (int pl = 0; pl < NP; ++pl) vp[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16 * pl, 0, 16);
+#endif
                     }
                 };
 #ifdef PGASR_LSTM_DIAG
@@ -733,19 +746,26 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
 #endif
             {
                 // publish h_t (also after the last step: nobody reads that slot, and lstm_prepare_kernel resets it): each cell
-                // thread writes its own bf16 planes (2-byte stores); layout [kc = unit/8][n][plane][unit%8] of this member's block
+                // thread writes its own bf16 planes (2-byte stores); layout [kc = unit/8][plane][n][unit%8] of this member's block
                 const unsigned e = (unsigned)(step >> 1) & 1u;
                 const unsigned tb = (pu & 1) ? (1u - e) : e;
                 unsigned short hp[NP];
                 split_planes_tagged<NP>(h, tb, hp);
+#if PGASR_FWD_XLAYOUT
+                const unsigned off = (unsigned)(step & 1) * SLOT + (unsigned)g * (512u * NP) +
+                                     (unsigned)(((pu >> 3) * NP * 16 + pn) * 16 + (pu & 7) * 2);
+                constexpr unsigned PSTRIDE = 256;      // plane stride inside a kc block: 16 n x 16 B
+#else
                 const unsigned off = (unsigned)(step & 1) * SLOT + (unsigned)g * (512u * NP) +
                                      (unsigned)((((pu >> 3) * 16 + pn) * NP) * 16 + (pu & 7) * 2);
+                constexpr unsigned PSTRIDE = 16;
+#endif
                 if (same_xcd) {
 #pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) __builtin_amdgcn_raw_buffer_store_b16(hp[pl], rsrc, off + 16 * pl, 0, 0);
+                    for (int pl = 0; pl < NP; ++pl) __builtin_amdgcn_raw_buffer_store_b16(hp[pl], rsrc, off + PSTRIDE * pl, 0, 0);
                 } else {
 #pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) __builtin_amdgcn_raw_buffer_store_b16(hp[pl], rsrc, off + 16 * pl, 0, 16);
+                    for (int pl = 0; pl < NP; ++pl) __builtin_amdgcn_raw_buffer_store_b16(hp[pl], rsrc, off + PSTRIDE * pl, 0, 16);
                 }
             }
             STAMP(5);

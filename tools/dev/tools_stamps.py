@@ -14,6 +14,7 @@ for d in range(2):
     params += [torch.randn(1024, 512, generator=g) * 0.05, (torch.rand(1024, 256, generator=g) * 2 - 1) / 16,
                torch.zeros(1024), torch.zeros(1024)]
 params = [p.to(dev) for p in params]
+hipops.set_precision(os.environ.get("PREC", "bf16x3"))      # "f32": the three-plane / six-product sweep (NP = 3)
 wih, bias, pf, pb = hipops.lstm_pack(params, 512)
 gates = torch.randn(T, B, 2048, generator=g).to(dev)
 out = torch.empty(T, B, 512, device=dev); cbuf = torch.empty(T, B, 512, device=dev)

@@ -10,6 +10,7 @@ params = []
 for d in range(2):
     params += [torch.randn(1024, 512, generator=g) * 0.05, (torch.rand(1024, 256, generator=g) * 2 - 1) / 16, torch.zeros(1024), torch.zeros(1024)]
 params = [p.to(dev) for p in params]
+hipops.set_precision(os.environ.get("PREC", "bf16x3"))      # "f32": three planes / six products
 wih, bias, pf, pb = hipops.lstm_pack(params, 512)
 gates0 = torch.randn(T, B, 2048, generator=g).to(dev)
 out = torch.empty(T, B, 512, device=dev); cbuf = torch.empty(T, B, 512, device=dev)
@@ -27,4 +28,4 @@ for bwd in (False, True):
     e1.record(); torch.cuda.synchronize()
     res.append(e0.elapsed_time(e1) / 3)
 hipops.lstm_assert_no_timeouts()
-print(f"flags {hipops.LSTM_FLAGS:#x}: fwd {res[0]:.3f} ms   bwd {res[1]:.3f} ms", flush=True)
+print(f"{hipops.get_precision()} flags {hipops.LSTM_FLAGS:#x}: fwd {res[0]:.3f} ms   bwd {res[1]:.3f} ms", flush=True)
