@@ -266,6 +266,14 @@ int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int lda, const 
                             const unsigned* xcc_busy, unsigned* tiles_done, int order,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* The reference's attention context (model.py:58-94, Attention.forward, AS EXECUTED -- csrc/attention.hip):
+ *   ctx[q,k] = sum_i e[b,i,k] * (sum_r exp(d[q,r] e[b,i,k])) / (sum_k' exp(d[q,k] e[b,i,k'])),   b = q % B
+ * dec (NQ x H) decoder states -- NQ = L * B rows in (step, utterance) order, or just B rows for one step --, enc (B x T x H) encoder
+ * outputs, ctx (NQ x H).  The denominator is the reference's own: model.py:73 divides the (H,H) outer-product matrix by its row
+ * sums lined up with the LAST axis (entry [r,k] by row k's sum).  Every encoder frame counts (no mask), H_dec == H_enc.  fp32,
+ * exponent maxima taken out exactly.  A defined function for parity, not a hot kernel (2 H exponentials per output and frame). */
+int pgasr_attention_ctx(const float* dec, const float* enc, int NQ, int B, int T, int H, float* ctx, void* stream);
+
 size_t pgasr_colsum_workspace_bytes(int rows, int cols);
 int pgasr_colsum_f32(const float* X, int rows, int cols, int ld, float* out, float* out2, int accumulate,
                      void* workspace, size_t workspace_bytes, void* stream);

@@ -21,6 +21,23 @@
 #include "x3w_common.h"
 #include <type_traits>
 
+// Diagnostic build only (make diag: -DPGASR_X6_DIAG; results invalid): PGASR_X6_DIAG=<bits> switches parts of the plain x6c kernel's
+// k-loop off -- 1 no W DMA, 2 no MFMA, 4 no A loads, 8 no conversion, 16 no fragment reads, 32 no per-step barrier
+#ifdef PGASR_X6_DIAG
+#define X6D(bit) (!FEED && (g.single & (bit)))
+// in-kernel stamps (diagnostic build): every wave of workgroup 0 accumulates the cycles between consecutive stamps per segment
+__device__ long long x6_stamp_out[8][16];
+#define X6STAMP_DECL long long st_last_ = clock64(); long long st_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const long long st_c0_ = clock64(), st_r0_ = wall_clock64()
+#define X6STAMP(slot) do { const long long now_ = clock64(); st_acc_[slot] += now_ - st_last_; st_last_ = now_; } while (0)
+#define X6STAMP_FLUSH() do { if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) { for (int i_ = 0; i_ < 12; ++i_) x6_stamp_out[w][i_] = st_acc_[i_]; \
+                             x6_stamp_out[w][12] = clock64() - st_c0_; x6_stamp_out[w][13] = wall_clock64() - st_r0_; } } while (0)
+#else
+#define X6D(bit) false
+#define X6STAMP_DECL
+#define X6STAMP(slot) do { } while (0)
+#define X6STAMP_FLUSH() do { } while (0)
+#endif
+
 namespace {
 namespace x6c {
 constexpr int TM = 256, TN = 256, TK = 16, THREADS = 512;
@@ -103,13 +120,20 @@ __device__ __forceinline__ void mfma6(f32x16 (&acc)[2], const u32x4_t (&a)[3], c
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[PA[p]]), __builtin_bit_cast(bf16x8_t, b[j][PB[p]]), acc[j], 0, 0, 0);
 }
 
-// VAR (PGASR_X6_VAR, read at every call; results identical): 0 = fragments of two row tiles read, waited for, multiplied
-// (gemm_c256.hip's structure); 1 = the fragments of row tile i + 1 are read while row tile i is multiplied (a wave's LDS latency
-// under its own MFMAs instead of its SIMD partner's); 2 = 1 with the A conversion in two halves behind different row tiles
+// VAR (PGASR_X6_VAR, read at every call; bit-identical results): 7 (default) = SELF-INTERLEAVED, every wave carries its own non-MFMA
+// work as fillers behind its own MFMAs; 0 = gemm_c256.hip's structure (two row tiles' fragments read, waited for, multiplied; the
+// conversion as a block, the two waves of a SIMD half a step out of phase).  Round 4 measured five more structures on one box --
+// fragment reads pipelined one row tile ahead (1), that with the conversion in two halves (2), PING-PONG roles with a barrier
+// between the phases (3), without it (4), with s_setprio 3 on the memory phase (5), VAR 0 with s_setprio 3 around the conversion
+// (6) -- all within +-3 % of VAR 0 (410-440 us on the two shapes).  In-kernel stamps said why: while one wave of a SIMD issues
+// back-to-back MFMAs its partner gets about ONE instruction per MFMA (a 44-VALU conversion beside the partner's 48 MFMAs took 1,880
+// cycles, whatever the priorities), so a "memory phase beside a multiply phase" does not overlap -- with the k-loop's pieces switched
+// off in turn, MFMA + fragment reads alone took 322 us, everything but the MFMAs 180 us, together 410: they ADD.  And a whole
+// chip of bare v_mfma_f32_32x32x16_bf16 on random operands sustains 1.7-1.9 PF at 1.7-1.86 GHz (tools/mfma_peak.hip), not 2.5.
 template <bool FEED, int VAR>
 __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];   // the ONLY LDS object
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;      // (w made wave-uniform for the compiler -- readfirstlane -- spills: measured, not kept)
     const int wm = w >> 2, wn = w & 3;
     const int nk = g.K / TK;
     if (FEED && g.xcc_busy) {       // a workgroup on one of the sweep's XCDs leaves at once (placement is read, not assumed)
@@ -158,6 +182,7 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
         pw[0] = g.Whi + o; pw[1] = g.Wmid + o; pw[2] = g.Wlo + o;
     }
     auto issue_w1 = [&](int kt, int stage, int plane) {     // one of a step's three W pieces
+        if (X6D(1) && kt >= kt0 + NW - 1) return;
         const int k0 = (kt < nk ? kt : nk - 1) * TK;
         dma16(pw[plane] + k0, smem + LDS_W + stage * WSTAGE_BYTES + plane * WP_BYTES + w * 1024);
     };
@@ -168,6 +193,7 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
     typedef std::integral_constant<int, 2> I2;
     auto load_a1 = [&](int kt, auto setc, int j) {      // ONE of a step's two A loads (k clamped: always issued, the counted waits are exact)
         const unsigned kb = (unsigned)((kt < nk ? kt : nk - 1) * TK * 4);
+        if (X6D(4) && kt >= kt0 + NA + 1) return;
         if (j == 0) load_a_one<0>(araw[decltype(setc)::value], aoff, kb, g.A);
         else load_a_one<1>(araw[decltype(setc)::value], aoff, kb, g.A);
     };
@@ -175,9 +201,14 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
     auto convert_a1 = [&](int buf, auto setc, int j) {    // one of a register set's two rows -> the three planes of buffer `buf`
         constexpr int S = decltype(setc)::value;
         const unsigned base = lds0 + (unsigned)buf * ABUF_BYTES;
+        if (X6D(8)) return;
         unsigned h0, m0_, l0, h1, m1_, l1;
-        split3(__uint_as_float(araw[S][j].x), __uint_as_float(araw[S][j].y), h0, m0_, l0);
-        split3(__uint_as_float(araw[S][j].z), __uint_as_float(araw[S][j].w), h1, m1_, l1);
+        if (X6D(128)) { h0 = araw[S][j].x; h1 = araw[S][j].y; m0_ = araw[S][j].z; m1_ = araw[S][j].w; l0 = h0; l1 = h1; }      // 128: no split arithmetic
+        else {
+            split3(__uint_as_float(araw[S][j].x), __uint_as_float(araw[S][j].y), h0, m0_, l0);
+            split3(__uint_as_float(araw[S][j].z), __uint_as_float(araw[S][j].w), h1, m1_, l1);
+        }
+        if (X6D(64)) { asm volatile("" :: "v"(h0), "v"(h1), "v"(m0_), "v"(m1_), "v"(l0), "v"(l1)); return; }                     // 64: no LDS stores
         write_planes3(base + apw[j], h0, h1, m0_, m1_, l0, l1);
     };
     auto convert_a = [&](int buf, auto setc) { convert_a1(buf, setc, 0); convert_a1(buf, setc, 1); };
@@ -203,6 +234,7 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    X6STAMP_DECL;
 
     // one half of a step: row tiles 2 HALF, 2 HALF + 1 against both column tiles = 24 MFMAs; `mem(0)` runs behind the first
     // twelve, `mem(1)` behind the last twelve (the step's five memory instructions are spread over its four twelve-MFMA
@@ -211,12 +243,14 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
         constexpr int HALF = decltype(halfc)::value;
         const unsigned ab = lds0 + (unsigned)cur * ABUF_BYTES, wb = lds0 + (unsigned)wst * WSTAGE_BYTES;
         Planes2 fa;
-        if (HALF == 0) read_pair(fb, wb + offB[0], wb + offB[1]);
-        read_pair(fa, ab + offA[2 * HALF], ab + offA[2 * HALF + 1]);
+        if (!X6D(16)) {
+            if (HALF == 0) read_pair(fb, wb + offB[0], wb + offB[1]);
+            read_pair(fa, ab + offA[2 * HALF], ab + offA[2 * HALF + 1]);
+        }
         if (HALF == 0) wait_pairs(fa, fb); else wait_pair(fa);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            mfma6(acc[2 * HALF + i], fa[i], fb);
+            if (!X6D(2)) mfma6(acc[2 * HALF + i], fa[i], fb);
             __builtin_amdgcn_sched_barrier(0);
             mem(i);
             __builtin_amdgcn_sched_barrier(0);
@@ -247,68 +281,136 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
         auto mem_a = [&](int s) { load_a1(kt + 1 + NA, setc, s); };
         Planes2 fb;
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (VAR >= 1) {
-            // row tile i + 1's fragments are read while row tile i is multiplied; waves 0-3 (EARLY) convert before row 0 (VAR 2: half
-            // of it behind row 0), waves 4-7 behind row 1 (VAR 2: and row 2) -- the two waves of a SIMD never convert together
-            auto body = [&](auto earlyc) {
-                constexpr bool EARLY = decltype(earlyc)::value;
-                const unsigned ab = lds0 + (unsigned)cur * ABUF_BYTES, wb = lds0 + (unsigned)wst * WSTAGE_BYTES;
-                u32x4_t f0[3], f1[3];
-                auto conv = [&](int part) {          // part 0 / 1: the conversion's first / second half (VAR 1: all of it in part 0)
-                    if (part == 0) {
-                        wait_a_regs<EARLY ? 10 : 13>(araw[decltype(setc)::value]);
-                        convert_a1(cur ^ 1, setc, 0);
-                        if (VAR == 1) convert_a1(cur ^ 1, setc, 1);
-                    } else if (VAR == 2) convert_a1(cur ^ 1, setc, 1);
-                };
-                if (EARLY) { conv(0); __builtin_amdgcn_sched_barrier(0); }
-                read_pair(fb, wb + offB[0], wb + offB[1]);
+        X6STAMP(0);
+        if constexpr (VAR == 7) {
+            // SELF-INTERLEAVED (round 4, after the stamps of the other structures: while one wave of a SIMD issues back-to-back MFMAs its
+            // partner gets about ONE instruction per MFMA -- a 44-VALU conversion beside the partner's 48 MFMAs took 1,880 cycles, with
+            // or without s_setprio -- so "one wave converts while the other multiplies" does not overlap, the phases ADD).  Here every
+            // wave carries its own non-MFMA work as fillers in its own MFMA gaps, a few instructions behind each MFMA: the fragment
+            // reads of the next row tile, the conversion in eight half-splits, the plane stores, the three W pieces, the two A loads.
+            // Both waves of a SIMD run the same stream in step; their MFMAs alternate on the pipe.
+            const unsigned ab = lds0 + (unsigned)cur * ABUF_BYTES, wb = lds0 + (unsigned)wst * WSTAGE_BYTES;
+            const unsigned cb = lds0 + (unsigned)(cur ^ 1) * ABUF_BYTES;
+            constexpr int S = decltype(setc)::value;
+            u32x4_t f0[3], f1[3];
+            unsigned hh[2], mm[2], ll[2];      // the packed planes of the row being converted: [pair]
+            float r0[2], r1[2];
+            auto split_a = [&](int j, int q) {      // stage A of a pair's 3-way split: hi, residual
+                const float x0 = __uint_as_float(q ? araw[S][j].z : araw[S][j].x), x1 = __uint_as_float(q ? araw[S][j].w : araw[S][j].y);
+                typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+                typedef __attribute__((ext_vector_type(2))) float f2;
+                hh[q] = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){x0, x1}, bf2));
+                r0[q] = x0 - __uint_as_float(hh[q] << 16); r1[q] = x1 - __uint_as_float(hh[q] & 0xFFFF0000u);
+            };
+            auto split_b = [&](int q) {             // stage B: mid, residual, lo
+                typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+                typedef __attribute__((ext_vector_type(2))) float f2;
+                mm[q] = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){r0[q], r1[q]}, bf2));
+                const float s0 = r0[q] - __uint_as_float(mm[q] << 16), s1 = r1[q] - __uint_as_float(mm[q] & 0xFFFF0000u);
+                ll[q] = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){s0, s1}, bf2));
+            };
+            // Row tiles are taken in the order 0 1 2 3 by waves 0-3 and 2 3 0 1 by waves 4-7, and the fillers ride on the FIRST two row
+            // slots of waves 0-3 and on the LAST two of waves 4-7: one wave's filler-laden MFMAs run beside its SIMD partner's bare ones.
+            auto filler = [&](int kind, int gp, int nextrow, u32x4_t (&fnext)[3]) {    // kind 0 / 1: first / second filler row, 2: bare row
+                if (gp == 0 && nextrow >= 0) read_row(fnext, ab + offA[nextrow]);
+                if (kind == 0) {
+                    if (gp == 1) wait_a_regs<10>(araw[S]);
+                    else if (gp == 2) split_a(0, 0);
+                    else if (gp == 3) split_b(0);
+                    else if (gp == 4) split_a(0, 1);
+                    else if (gp == 5) split_b(1);
+                    else if (gp == 6) { if (!X6D(8)) write_planes3(cb + apw[0], hh[0], hh[1], mm[0], mm[1], ll[0], ll[1]); }
+                    else if (gp == 7) issue_w1(kw, sw, 0);
+                    else if (gp == 8) issue_w1(kw, sw, 1);
+                    else if (gp == 9) issue_w1(kw, sw, 2);
+                } else if (kind == 1) {
+                    if (gp == 1) split_a(1, 0);
+                    else if (gp == 2) split_b(0);
+                    else if (gp == 3) split_a(1, 1);
+                    else if (gp == 4) split_b(1);
+                    else if (gp == 5) { if (!X6D(8)) write_planes3(cb + apw[1], hh[0], hh[1], mm[0], mm[1], ll[0], ll[1]); }
+                    else if (gp == 6) load_a1(kt + 1 + NA, setc, 0);
+                    else if (gp == 7) load_a1(kt + 1 + NA, setc, 1);
+                }
+            };
+            auto row_mfma = [&](auto rowc, auto kindc, auto nextc, u32x4_t (&fa)[3], u32x4_t (&fnext)[3]) {
+                constexpr int ROW = decltype(rowc)::value, KIND = decltype(kindc)::value, NEXT = decltype(nextc)::value;
+                constexpr int PA[6] = {0, 0, 1, 0, 2, 1}, PB[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+                for (int m = 0; m < 12; ++m) {
+                    const int pp = m >> 1, j = m & 1;
+                    acc[ROW][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[PA[pp]]), __builtin_bit_cast(bf16x8_t, fb[j][PB[pp]]), acc[ROW][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    filler(KIND, m, NEXT, fnext);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            typedef std::integral_constant<int, 2> R2;
+            typedef std::integral_constant<int, 3> R3;
+            typedef std::integral_constant<int, -1> RN;
+            read_pair(fb, wb + offB[0], wb + offB[1]);
+            if (w < 4) {
                 read_row(f0, ab + offA[0]);
                 wait_row_pair(f0, fb);
-                read_row(f1, ab + offA[1]);
-                mfma6(acc[0], f0, fb);
-                __builtin_amdgcn_sched_barrier(0);
-                mem_w(0);
-                if (EARLY) conv(1);
-                __builtin_amdgcn_sched_barrier(0);
+                X6STAMP(3);
+                row_mfma(I0{}, I0{}, I1{}, f0, f1);
                 wait_row(f1);
-                read_row(f0, ab + offA[2]);
-                mfma6(acc[1], f1, fb);
-                __builtin_amdgcn_sched_barrier(0);
-                mem_w(1);
-                if (!EARLY) conv(0);
-                __builtin_amdgcn_sched_barrier(0);
+                X6STAMP(1);
+                row_mfma(I1{}, I1{}, R2{}, f1, f0);
                 wait_row(f0);
-                read_row(f1, ab + offA[3]);
-                mfma6(acc[2], f0, fb);
-                __builtin_amdgcn_sched_barrier(0);
-                mem_a(0);
-                if (!EARLY) conv(1);
-                __builtin_amdgcn_sched_barrier(0);
+                X6STAMP(4);
+                row_mfma(R2{}, R2{}, R3{}, f0, f1);
                 wait_row(f1);
-                mfma6(acc[3], f1, fb);
-                __builtin_amdgcn_sched_barrier(0);
-                mem_a(1);
-            };
-            if (w < 4) body(std::true_type{}); else body(std::false_type{});
+                X6STAMP(5);
+                row_mfma(R3{}, R2{}, RN{}, f1, f0);
+                X6STAMP(6);
+            } else {
+                read_row(f0, ab + offA[2]);
+                wait_row_pair(f0, fb);
+                X6STAMP(3);
+                row_mfma(R2{}, R2{}, R3{}, f0, f1);
+                wait_row(f1);
+                X6STAMP(1);
+                row_mfma(R3{}, R2{}, I0{}, f1, f0);
+                wait_row(f0);
+                X6STAMP(4);
+                row_mfma(I0{}, I0{}, I1{}, f0, f1);
+                wait_row(f1);
+                X6STAMP(5);
+                row_mfma(I1{}, I1{}, RN{}, f1, f0);
+                X6STAMP(6);
+            }
         } else if (w < 4) {
             wait_a_regs<10>(araw[decltype(setc)::value]);
+            X6STAMP(3);
             convert_a(cur ^ 1, setc);
             __builtin_amdgcn_sched_barrier(0);
+            X6STAMP(4);
             half_step(cur, wst, I0{}, fb, mem_w);
+            X6STAMP(1);
             half_step(cur, wst, H1{}, fb, mem_a);
+            X6STAMP(10);
         } else {
             half_step(cur, wst, I0{}, fb, mem_w);
             __builtin_amdgcn_sched_barrier(0);
+            X6STAMP(1);
             wait_a_regs<13>(araw[decltype(setc)::value]);     // .. plus the three W pieces just issued
+            X6STAMP(3);
             convert_a(cur ^ 1, setc);
             __builtin_amdgcn_sched_barrier(0);
+            X6STAMP(4);
             half_step(cur, wst, H1{}, fb, mem_a);
+            X6STAMP(10);
         }
         __builtin_amdgcn_sched_barrier(0);
         // my W pieces of step kt + 1 have landed (behind them: A(kt+2) W(kt+2) A(kt+3) W(kt+3) A(kt+4) = 12), my plane stores are done
-        asm volatile("s_waitcnt vmcnt(12)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        X6STAMP(7);
+        if (X6D(1 | 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        X6STAMP(8);
+        if (!X6D(32)) __builtin_amdgcn_s_barrier();
+        X6STAMP(9);
         asm volatile("" ::: "memory");
     };
     for (int kt = kt0; kt < kt1; kt += 3) {        // A(kt + 1) sits in set (kt - kt0 + 1) % 3
@@ -319,6 +421,8 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the loads of the steps behind the last one (discarded)
 #pragma unroll
     for (int s = 0; s < NA; ++s) asm volatile("" : "+v"(araw[s][0]), "+v"(araw[s][1]));
+    X6STAMP(11);
+    X6STAMP_FLUSH();
 
     if (FEED && qpart >= 0) {
         // one quarter of a split tile: park the accumulators (thread-major: a wave instruction stores 256 contiguous
@@ -428,7 +532,9 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned short* p) {
     return __builtin_bit_cast(bf16x8_t, (s16x8_t){a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w});
 }
 
-template <bool GATED>
+// PP (PGASR_T6_VAR): 0 = the two waves of a SIMD half a step out of phase (t256's arrangement); 1 = ping-pong -- waves 0-3 multiply
+// while waves 4-7 convert and load, a barrier, then the other way round; 2 = the same without the barrier in the middle
+template <bool GATED, int PP>
 __global__ __launch_bounds__(THREADS) void gemm_t6_kernel(PgasrTn256Args g0, PgasrTn256Args g1) {
     extern __shared__ __attribute__((aligned(128))) unsigned short S[];      // the ONLY LDS object: [buffer][A hi, mid, lo, B hi, mid, lo][k][PITCH]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -597,7 +703,13 @@ __global__ __launch_bounds__(THREADS) void gemm_t6_kernel(PgasrTn256Args g0, Pga
     auto step = [&](int kt, auto setc) {               // setc: the register set that holds step kt + 1
         const int cur = kt & 1;
         bf16x8_t bf[2][3];
-        if (w < 4) {
+        if constexpr (PP >= 1) {
+            if (w < 4) { if (mul) { multiply(cur, I0{}, bf); multiply(cur, I1{}, bf); } }
+            else if (mem) { if (kt + 1 < nk) convert(cur ^ 1, setc); load(kt + 3, setc); }
+            if (PP == 1) T6_BARRIER();
+            if (w >= 4) { if (mul) { multiply(cur, I0{}, bf); multiply(cur, I1{}, bf); } }
+            else if (mem) { if (kt + 1 < nk) convert(cur ^ 1, setc); load(kt + 3, setc); }
+        } else if (w < 4) {
             if (mem) { if (kt + 1 < nk) convert(cur ^ 1, setc); load(kt + 3, setc); }
             if (mul) { multiply(cur, I0{}, bf); multiply(cur, I1{}, bf); }
         } else {
@@ -650,12 +762,18 @@ __global__ __launch_bounds__(256) void split_planes3_kernel(const float* __restr
 
 static int x6_var() {       // PGASR_X6_VAR (read at every call: A/B inside one process); default: see the kernel's header
     const char* e = getenv("PGASR_X6_VAR");
-    return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0;
+    return (e && e[0] == '0') ? 0 : 7;
 }
 constexpr int X6_FEED_SPLIT_MAX = 32;      // split tiles per feed: 4 x 32 slabs of 256 KB = 32 MB of workspace
 int x6_quarters(int K) { return (K >= 1024 && K % (4 * x6c::TK) == 0) ? 4 : 1; }
 
 }  // namespace
+
+#ifdef PGASR_X6_DIAG
+extern "C" int pgasr_diag_x6_stamps(long long* out) {      // host copy of workgroup 0's stamps: [wave 8][16]
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(x6_stamp_out), sizeof(long long) * 8 * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int pgasr_split_bf16_planes3(const float* src, int rows, int cols, int ld, int transpose,
                                         unsigned short* hi, unsigned short* mid, unsigned short* lo, void* stream) {
@@ -681,10 +799,13 @@ extern "C" int pgasr_gemm_x6w_f32(int M, int N, int K, const float* A, int lda, 
     if (!x6w_shape_ok(M, N, K, A, lda, ldc, Whi, Wmid, Wlo)) return PGASR_ERR_UNSUPPORTED;
     const size_t lds = (size_t)x6c::LDS_BYTES;
     const int var = x6_var();
-    auto kern = var == 2 ? x6c::gemm_x6c_kernel<false, 2> : var == 1 ? x6c::gemm_x6c_kernel<false, 1> : x6c::gemm_x6c_kernel<false, 0>;
+    auto kern = var == 7 ? x6c::gemm_x6c_kernel<false, 7> : x6c::gemm_x6c_kernel<false, 0>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
     DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, dact_y, slope, nullptr, nullptr, nullptr, 0, 0, 0, 1, 0, nullptr, nullptr, 0, Wmid};
+#ifdef PGASR_X6_DIAG
+    if (const char* e = getenv("PGASR_X6_DIAG")) g.single = atoi(e);
+#endif
     PGASR_LAUNCH_KERNEL(kern, dim3((unsigned)(N / x6c::TN), (unsigned)((M + x6c::TM - 1) / x6c::TM)), dim3(x6c::THREADS), lds,
                         (hipStream_t)stream, g);
     PGASR_CHECK_LAUNCH();
@@ -709,7 +830,7 @@ extern "C" int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int 
     const int mt = (M + x6c::TM - 1) / x6c::TM, nt = N / x6c::TN;
     const size_t lds = (size_t)x6c::LDS_BYTES + 16;
     const int var = x6_var();
-    auto kern = var == 2 ? x6c::gemm_x6c_kernel<true, 2> : var == 1 ? x6c::gemm_x6c_kernel<true, 1> : x6c::gemm_x6c_kernel<true, 0>;
+    auto kern = var == 7 ? x6c::gemm_x6c_kernel<true, 7> : x6c::gemm_x6c_kernel<true, 0>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
     if (hipMemsetAsync(workspace, 0, 1024, st) != hipSuccess) return PGASR_ERR_LAUNCH;     // tile counter + arrival counters
@@ -743,22 +864,26 @@ int pgasr_internal_tn6_launch(PgasrTn256Args a, int masked_then_unmasked, hipStr
         b = *second;
     }
     const size_t lds = (size_t)t6::LDS_BYTES;
-    if (hipFuncSetAttribute((const void*)t6::gemm_t6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    const char* ev = getenv("PGASR_T6_VAR");
+    const int pp = (ev && ev[0] >= '0' && ev[0] <= '2') ? ev[0] - '0' : 0;
+    auto kplain = pp == 2 ? t6::gemm_t6_kernel<false, 2> : pp == 1 ? t6::gemm_t6_kernel<false, 1> : t6::gemm_t6_kernel<false, 0>;
+    auto kgated = pp == 2 ? t6::gemm_t6_kernel<true, 2> : pp == 1 ? t6::gemm_t6_kernel<true, 1> : t6::gemm_t6_kernel<true, 0>;
+    if (hipFuncSetAttribute((const void*)kplain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
     const unsigned nitems = (unsigned)((a.N / t6::TN) * (a.M / t6::TM)) * (unsigned)(a.batch * a.splitk);
     if (!a.queue) {
-        PGASR_LAUNCH_KERNEL(t6::gemm_t6_kernel<false>, dim3(nitems), dim3(t6::THREADS), lds, st, a, b);
+        PGASR_LAUNCH_KERNEL(kplain, dim3(nitems), dim3(t6::THREADS), lds, st, a, b);
         PGASR_CHECK_LAUNCH();
         return PGASR_OK;
     }
-    if (a.gate && hipFuncSetAttribute((const void*)t6::gemm_t6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (a.gate && hipFuncSetAttribute((const void*)kgated, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
     const unsigned* busy = a.xcc_busy;
     for (int pass = 0; pass < ((masked_then_unmasked && busy) ? 2 : 1); ++pass) {
         a.xcc_busy = (pass == 0) ? busy : nullptr;
         b.xcc_busy = a.xcc_busy;
-        if (a.gate) PGASR_LAUNCH_KERNEL(t6::gemm_t6_kernel<true>, dim3(256), dim3(t6::THREADS), lds, st, a, b);
-        else        PGASR_LAUNCH_KERNEL(t6::gemm_t6_kernel<false>, dim3(256), dim3(t6::THREADS), lds, st, a, b);
+        if (a.gate) PGASR_LAUNCH_KERNEL(kgated, dim3(256), dim3(t6::THREADS), lds, st, a, b);
+        else        PGASR_LAUNCH_KERNEL(kplain, dim3(256), dim3(t6::THREADS), lds, st, a, b);
         PGASR_CHECK_LAUNCH();
     }
     return PGASR_OK;

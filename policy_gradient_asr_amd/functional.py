@@ -42,6 +42,7 @@ class grad_overlap:
     stream wait for the side stream; call it after loss.backward()."""
     enabled = False
     confine = os.environ.get("PGASR_CONFINE", "1") != "0"     # keep side-stream GEMMs off the XCDs of the concurrent LSTM sweep
+    confine_feed = os.environ.get("PGASR_CONFINE_FEED", "1") != "0"   # .. and the GEMMs that FEED a sweep (A/B switch)
     _sides = {}        # one side stream and one pending list PER main stream (micro-batches run on their own streams)
     _pendings = {}     # (ready event, closure) of the layer above, issued right AFTER the next sweep is launched
 
@@ -360,7 +361,8 @@ class BLSTMLayerFn(torch.autograd.Function):
             busy = hipops.lstm_busy_ptr(T, B, False, x.device)
             with torch.cuda.stream(side):
                 hipops.stream_gate(busy)
-                hipops.gemm_x3w_feed(x, prepacked.planes, gates, T * B, G, I, bias_perm, busy, done, phase=2 if head else 0, ws=ws_feed)
+                hipops.gemm_x3w_feed(x, prepacked.planes, gates, T * B, G, I, bias_perm, busy if grad_overlap.confine_feed else 0, done,
+                                     phase=2 if head else 0, ws=ws_feed)
             if ws_feed is not None:
                 streams.hold(ws_feed, side)
             for t_ in (x, gates, done, bias_perm) + tuple(prepacked.planes):
@@ -479,7 +481,7 @@ class BLSTMLayerFn(torch.autograd.Function):
                 return False
 
             def launch(busy_ptr, dg=dg, dx=dx, done=done, planes_t=planes_t):
-                hipops.gemm_x3w_feed(dg, planes_t, dx, T * B, I, G, None, busy_ptr, done, order=1,
+                hipops.gemm_x3w_feed(dg, planes_t, dx, T * B, I, G, None, busy_ptr if grad_overlap.confine_feed else 0, done, order=1,
                                      phase=2 if feed_ws else 0, ws=feed_ws[0] if feed_ws else None)
                 side_ = torch.cuda.current_stream()
                 for t_ in (dg, dx, done) + tuple(planes_t) + tuple(feed_ws):

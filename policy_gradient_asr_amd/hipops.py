@@ -691,6 +691,25 @@ def lstm_error_word_tensors(device):
 
 
 # ------------------------------------------------------------------------------------------
+# attention context of the reference's seq2seq decoder (model.py:58-94)
+# ------------------------------------------------------------------------------------------
+def attention_ctx(dec, enc):
+    """dec (NQ,H) or (L,B,H) decoder states (row q belongs to utterance q % B), enc (B,T,H) -> ctx with dec's shape:
+    Attention.forward of the reference as executed (include/pgasr_hip.h, pgasr_attention_ctx)."""
+    lib = _lib.load()
+    _req(dec, torch.float32, "dec"); _req(enc, torch.float32, "enc")
+    if enc.dim() != 3 or dec.shape[-1] != enc.shape[2]:
+        raise _lib.PgasrError("attention_ctx: enc (B,T,H) and dec (..., H) with the same H (model.py:69: the bmm output is (H,H))")
+    B, T, H = enc.shape
+    NQ = dec.numel() // H
+    if NQ % B:
+        raise _lib.PgasrError("attention_ctx: dec must hold a multiple of B rows")
+    ctx = torch.empty_like(dec)
+    _lib.check(lib.pgasr_attention_ctx(_p(dec), _p(enc), NQ, B, T, H, _p(ctx), _stream()), "pgasr_attention_ctx")
+    return ctx
+
+
+# ------------------------------------------------------------------------------------------
 # prefix beam search
 # ------------------------------------------------------------------------------------------
 def ctc_beam_search(log_probs, lengths=None, beam=5, blank=0, collapse=False, out=None, generic=False):

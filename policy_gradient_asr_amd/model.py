@@ -93,25 +93,61 @@ class Encoder(nn.Module):
 
 
 class Attention(nn.Module):
-    """Signature only (model.py:58-94); the attention decoder is out of scope."""
+    """model.py:58-94 as executed, on the MI355X (csrc/attention.hip, ``pgasr_attention_ctx``): per encoder frame the (H,H) outer
+    product exp(d[r] e_i[k]) divided by its row sums lined up with the LAST axis (model.py:73's broadcast -- entry [r,k] by row k's
+    sum; defect recorded in DESIGN.md), times the frame, summed over frames and over r.  dec_t (B,H), enc_out (B,T,H) -> (B,H).
+    Forward only: the reference never trains through it (``Decoder.forward`` returns None, model.py:117)."""
 
     def __init__(self):
         super().__init__()
 
     def forward(self, dec_t, enc_out):
-        raise NotImplementedError("attention decoder is out of scope of the CTC/policy-gradient path")
+        from . import hipops
+        return hipops.attention_ctx(dec_t.contiguous(), enc_out.contiguous())
 
 
 class Decoder(nn.Module):
-    """Signature only (model.py:99-117): Decoder(alphabet_size, hidden_size)."""
+    """model.py:99-117: Decoder(alphabet_size, hidden_size) -- embedding(128) -> one-layer LSTM(128 -> hidden) -> per decoder step
+    the attention context -> cat(dec_out[:, t], c_t).  Same parameter names / shapes as the reference (``embed_layer.weight``,
+    ``lstm.*_l0``; ``nn.LSTM`` is a parameter container here, never called: its cuDNN/MIOpen path is not used).
+    DOCUMENTED DIVERGENCE (like ``Seq2Seq.forward``): the reference builds the list `preds`, prints the shape of its stack and returns
+    None (model.py:112-117); this returns that stack, (L, B, 2 * hidden), and prints nothing.  Forward only.
+    The recurrent part is L dependent steps of (B,hidden) x (hidden,4 hidden) on the exact fp32 MFMA GEMM plus pointwise gates --
+    the BLSTM sweep kernels are built for H = 256 bidirectional layers and do not take this shape."""
 
     def __init__(self, alphabet_size, hidden_size):
         super().__init__()
         self.alphabet_size = alphabet_size
         self.hidden_size = hidden_size
+        self.embed_layer = nn.Embedding(alphabet_size, 128)
+        self.lstm = nn.LSTM(input_size=128, hidden_size=hidden_size, num_layers=1, batch_first=True)   # reference: dropout=0.3, a no-op with one layer
+        self.attn = Attention()
 
     def forward(self, target_inputs, encoder_outputs, device=None):
-        raise NotImplementedError("attention decoder is out of scope of the CTC/policy-gradient path")
+        from . import hipops
+        H = self.hidden_size
+        w_ih, w_hh = self.lstm.weight_ih_l0.detach().contiguous(), self.lstm.weight_hh_l0.detach().contiguous()
+        bias = (self.lstm.bias_ih_l0 + self.lstm.bias_hh_l0).detach().contiguous()
+        if not w_ih.is_cuda:
+            raise RuntimeError("Decoder.forward runs on the MI355X only (no CPU path)")
+        B, L = target_inputs.shape
+        x = self.embed_layer.weight.detach()[target_inputs.to(w_ih.device)].transpose(0, 1).contiguous()      # (L,B,128), time-major
+        xp = torch.empty(L * B, 4 * H, dtype=torch.float32, device=w_ih.device)
+        hipops.gemm(x.view(L * B, 128), w_ih, xp, M=L * B, N=4 * H, K=128, transB=True, bias=bias, precision=0)
+        xp = xp.view(L, B, 4 * H)
+        h = torch.zeros(B, H, dtype=torch.float32, device=w_ih.device)
+        c = torch.zeros_like(h)
+        g = torch.empty(B, 4 * H, dtype=torch.float32, device=w_ih.device)
+        dec_out = torch.empty(L, B, H, dtype=torch.float32, device=w_ih.device)
+        for t in range(L):
+            hipops.gemm(h, w_hh, g, M=B, N=4 * H, K=H, transB=True, precision=0)
+            g += xp[t]
+            i, f, gg, o = torch.sigmoid(g[:, :H]), torch.sigmoid(g[:, H:2 * H]), torch.tanh(g[:, 2 * H:3 * H]), torch.sigmoid(g[:, 3 * H:])
+            c = f * c + i * gg
+            h = (o * torch.tanh(c)).contiguous()
+            dec_out[t] = h
+        ctx = hipops.attention_ctx(dec_out, encoder_outputs.to(w_ih.device).contiguous())                       # (L,B,H): row q = t * B + b
+        return torch.cat((dec_out, ctx), dim=2)
 
 
 class Seq2Seq(nn.Module):

@@ -144,6 +144,69 @@ def gen_reward_defect():
     return {"probs": probs.tolist(), "true_y": "abc", "as_written": res, "decoded_collapsed": s}
 
 
+def _placeholders():
+    for name in ("torchaudio", "torchsummary", "cvutils"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            if name == "torchsummary":
+                m.summary = None
+            if name == "cvutils":
+                m.Validator = None
+                m.Alphabet = None
+            sys.modules[name] = m
+
+
+def gen_attention():
+    """model.Attention.forward (model.py:62-92) on seeded (B,H,T) cases and the `preds` list model.Decoder.forward builds
+    (model.py:109-116; the reference only prints its shape and returns None -- recorded) -> attention_cases.npz."""
+    import contextlib
+    import io
+    _placeholders()
+    import model as ref_model  # noqa: E402
+    attn = ref_model.Attention()
+    cases = {}
+    shapes = [(2, 64, 3), (2, 64, 17), (3, 128, 17), (2, 512, 50), (1, 512, 3), (4, 96, 50)]
+    for cid, (B, H, T) in enumerate(shapes):
+        g = torch.Generator().manual_seed(300 + cid)
+        d = torch.randn(B, H, generator=g) * 0.5
+        e = torch.randn(B, T, H, generator=g) * 0.5
+        with torch.no_grad():
+            c = attn(d, e)
+        cases[f"d{cid}"] = d.numpy(); cases[f"e{cid}"] = e.numpy(); cases[f"c{cid}"] = c.numpy()
+    # Decoder: V = 29, hidden 64 / 128 (H must equal the encoder feature size; small cases keep the fixture small); preds captured by running the sub-modules in the
+    # reference's own order (model.py:110-116), forward() itself called once to record its return value and what it prints
+    dec_meta = []
+    for did, (V, H, B, L, T) in enumerate([(29, 64, 2, 5, 7), (29, 128, 3, 4, 6)]):
+        torch.manual_seed(400 + did)
+        with warnings_off():
+            dec = ref_model.Decoder(V, H)
+        dec.eval()
+        g = torch.Generator().manual_seed(500 + did)
+        tgt = torch.randint(0, V, (B, L), generator=g)
+        enc = torch.randn(B, T, H, generator=g) * 0.5
+        buf = io.StringIO()
+        with torch.no_grad(), contextlib.redirect_stdout(buf):
+            ret = dec(tgt, enc)
+            x = dec.embed_layer(tgt)
+            dec_out, _ = dec.lstm(x)
+            preds = torch.stack([torch.cat((dec_out[:, t, :], dec.attn(dec_out[:, t, :], enc)), 1) for t in range(dec_out.shape[1])])
+        for k, v in dec.state_dict().items():
+            cases[f"dec{did}.{k}"] = v.numpy()
+        cases[f"dec{did}.targets"] = tgt.numpy(); cases[f"dec{did}.enc"] = enc.numpy(); cases[f"dec{did}.preds"] = preds.numpy()
+        dec_meta.append({"V": V, "H": H, "B": B, "L": L, "T": T, "forward_returns": repr(ret), "forward_prints": buf.getvalue().strip(),
+                         "state_dict": {k: list(v.shape) for k, v in dec.state_dict().items()}})
+    np.savez_compressed(os.path.join(HERE, "attention_cases.npz"), **cases)
+    return {"attention_shapes_BHT": shapes, "decoder": dec_meta}
+
+
+@__import__("contextlib").contextmanager
+def warnings_off():
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")      # nn.LSTM(num_layers=1, dropout=0.3) warns (model.py:103-106)
+        yield
+
+
 def gen_encoder():
     for name in ("torchaudio", "torchsummary", "cvutils"):
         if name not in sys.modules:
@@ -192,6 +255,7 @@ def main():
         "custom_nll": gen_nll(),
         "reward_defect": gen_reward_defect(),
         "encoder": gen_encoder(),
+        "attention": gen_attention(),
     }
     with open(os.path.join(HERE, "reference_vectors.json"), "w") as fo:
         json.dump(meta, fo, indent=0)

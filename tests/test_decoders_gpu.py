@@ -183,3 +183,41 @@ def test_reward_dropin(vectors):
     assert reward(y, probs, len(s) + 3, ind2char, dec) == 0
     with pytest.raises(ValueError):
         reward(y, probs, 0, ind2char, dec)
+
+
+def test_attention_and_decoder_vs_reference_golden(golden_dir):
+    """N4: ``model.Attention.forward`` / ``model.Decoder.forward`` of the reference (model.py:58-117), run here when the fixtures were
+    made (tests/golden/make_golden.py), against the HIP attention-context kernel and the device-side decoder -- including the
+    reference's broadcasting quirk (entry [r,k] divided by row k's sum).  1e-3 relative (measured ~1e-6)."""
+    import numpy as np
+    from oracle import attn_ref
+    from policy_gradient_asr_amd import hipops
+    from policy_gradient_asr_amd.model import Attention, Decoder
+    z = np.load(os.path.join(golden_dir, "attention_cases.npz"))
+    attn = Attention()
+    for cid in range(6):
+        d, e, c = z[f"d{cid}"], z[f"e{cid}"], z[f"c{cid}"]
+        got = attn(torch.from_numpy(d).to(DEV), torch.from_numpy(e).to(DEV)).cpu().numpy()
+        err = np.abs(got - c).max() / np.abs(c).max()
+        assert err < 1e-3, (cid, err)
+        assert np.abs(attn_ref.attention_ctx(d, e) - c).max() / np.abs(c).max() < 1e-5      # the oracle agrees with the reference too
+    # a textbook softmax attention would give something else: the quirk is really there
+    d, e = z["d1"].astype(np.float64), z["e1"].astype(np.float64)
+    x = np.einsum("br,bik->birk", d, e); a = np.exp(x); a = a / a.sum(-1, keepdims=True)
+    textbook = (a * e[:, :, None, :]).sum(axis=(1, 2))
+    assert np.abs(textbook - z["c1"]).max() / np.abs(z["c1"]).max() > 1e-2
+    for did in range(2):
+        pre = f"dec{did}."
+        sd = {k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre) and k[len(pre):] not in ("targets", "enc", "preds")}
+        V, H = sd["embed_layer.weight"].shape[0], sd["lstm.weight_hh_l0"].shape[1]
+        dec = Decoder(V, H)
+        dec.load_state_dict(sd, strict=True)          # the reference's own parameter names and shapes
+        dec = dec.to(DEV)
+        preds = dec(torch.from_numpy(z[pre + "targets"]), torch.from_numpy(z[pre + "enc"]).to(DEV))
+        want = z[pre + "preds"]
+        assert tuple(preds.shape) == want.shape
+        err = np.abs(preds.cpu().numpy() - want).max() / np.abs(want).max()
+        assert err < 1e-3, (did, err)
+    # NQ rows that are not a multiple of B are refused
+    with pytest.raises(Exception):
+        hipops.attention_ctx(torch.zeros(3, 64, device=DEV), torch.zeros(2, 5, 64, device=DEV))

@@ -222,3 +222,27 @@ def test_length_bucket_sampler():
     s.set_epoch(1)
     assert [b for b in s] != batches
     assert len(list(LengthBucketSampler(lengths, 8, drop_last=True))) == 25
+
+
+def test_attention_decoder_oracle_matches_reference(golden_dir, vectors):
+    """N4 oracle pin: oracle/attn_ref.py against the outputs of the reference's own ``model.Attention`` / ``model.Decoder`` (model.py:58-117)
+    recorded by tests/golden/make_golden.py -- the broadcasting quirk of model.py:73 included -- and what the reference's
+    ``Decoder.forward`` itself returns (None) and prints (the shape of the stack)."""
+    from oracle import attn_ref
+    z = np.load(os.path.join(golden_dir, "attention_cases.npz"))
+    meta = vectors["attention"]
+    assert len(meta["attention_shapes_BHT"]) == 6
+    for cid, (B, H, T) in enumerate(meta["attention_shapes_BHT"]):
+        d, e, c = z[f"d{cid}"], z[f"e{cid}"], z[f"c{cid}"]
+        assert d.shape == (B, H) and e.shape == (B, T, H) and c.shape == (B, H)
+        assert np.abs(attn_ref.attention_ctx(d, e) - c).max() / np.abs(c).max() < 1e-5
+    for did, m in enumerate(meta["decoder"]):
+        assert m["forward_returns"] == "None" and m["forward_prints"] == f"torch.Size([{m['L']}, {m['B']}, {2 * m['H']}])"
+        pre = f"dec{did}."
+        params = {k[len(pre):]: z[k] for k in z.files if k.startswith(pre) and k[len(pre):] not in ("targets", "enc", "preds")}
+        assert {k: list(v.shape) for k, v in params.items()} == m["state_dict"]
+        got = attn_ref.decoder_preds(params, z[pre + "targets"], z[pre + "enc"])
+        want = z[pre + "preds"]
+        assert got.shape == want.shape and np.abs(got - want).max() / np.abs(want).max() < 1e-5
+    with pytest.raises(ValueError):
+        attn_ref.attention_ctx(np.zeros((2, 8)), np.zeros((2, 3, 16)))
