@@ -32,8 +32,17 @@ import torch.distributed as dist  # noqa: E402
 
 B_PER_GPU, T, F, V, L = 32, 1000, 80, 29, 100
 METRIC = "utterances/sec (B=32,T=1000,F=80) policy-grad step, 1/2/4/8 MI355X"
-DTYPE = ("bf16x3 (fp32 storage and accumulate; every dense product = 3 bf16 MFMA terms hi*hi+hi*lo+lo*hi of a 2-plane split; the "
-         "fp32-faithful variant of the same step -- exact fp32 MFMA GEMMs, 3-plane / 6-product sweeps -- is timed beside it: precision_variants.f32)")
+# The arithmetic of the timed step is a mode of the host layer (hipops.PRECISION_MODES).  The DEFAULT is "f32": the reference computes in
+# torch fp32 (model.py:38-44), and that is what the headline `value` measures; "bf16x3" (within north_star's 1e-3 bar, ~1.35x
+# faster) is timed beside it in precision_variants.
+DTYPES = {
+    "f32": ("f32 (fp32-faithful: fp32 storage and accumulate; every big product -- recurrent sweeps, W_ih projections, input and weight "
+            "gradients -- on the bf16 MFMA as SIX terms of a 3-plane split hi/mid/lo, every term down to 2^-24 of the product; the small "
+            "products on the exact fp32 MFMA; the faster bf16x3 mode of the same step is timed beside it: precision_variants.bf16x3)"),
+    "bf16x3": ("bf16x3 (fp32 storage and accumulate; every dense product = 3 bf16 MFMA terms hi*hi+hi*lo+lo*hi of a 2-plane split; the "
+               "fp32-faithful mode of the same step is timed beside it: precision_variants.f32)"),
+}
+PRODUCTS = {"f32": 6, "bf16x3": 3}       # bf16 MFMA products issued per algorithmic fp32 multiply-add
 BF16_DENSE_PEAK_TF = 2500.0       # MI355X_MICROARCH.md, dense
 FP32_MFMA_PEAK_TF = 157.3
 STEP_GFLOP_PER_UTT = 28.65        # dense contraction forward + backward, T=1000
@@ -352,10 +361,11 @@ def parity_vs_fp64(model, trainer, batch, brief=False):
 
 
 # ------------------------------------------------------------------------------------------------
-def sweep_roofline(prof, n_sampled, frames_per_step):
+def sweep_roofline(prof, n_sampled, frames_per_step, products=3):
     """The dominant kernel's roofline figures from the HIP-event record of the SAMPLED steps: prof maps kernel name ->
     (total ms, launches) over n_sampled instrumented steps.  Algorithmic flops of one sweep launch: h (B,256) x W_hh^T
-    (256,1024), two directions, one multiply-add per frame of the chain."""
+    (256,1024), two directions, one multiply-add per frame of the chain.  products: bf16 MFMA products
+    the precision mode issues per algorithmic flop (3 or 6): the peak the algorithmic rate is priced against is 2500 / products."""
     sweeps = {k: v for k, v in prof.items() if k.startswith("lstm_")}
     name, (tot_ms, calls) = max(sweeps.items(), key=lambda kv: kv[1][0]) if sweeps else ("none", (0.0, 1))
     tavg = frames_per_step / B_PER_GPU                                # average steps of a sweep's chain
@@ -363,8 +373,72 @@ def sweep_roofline(prof, n_sampled, frames_per_step):
     avg_ms = tot_ms / max(calls, 1)
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     return {"kernel": name, "avg_launch_ms": avg_ms, "achieved": achieved,
-            "peak": BF16_DENSE_PEAK_TF / 3.0,          # 3 bf16 MFMA products per algorithmic fp32 flop
-            "flops_per_launch": flops_per_launch, "launches_per_step": calls / max(n_sampled, 1)}
+            "peak": BF16_DENSE_PEAK_TF / products,     # bf16 MFMA products per algorithmic fp32 flop: 3 (bf16x3) or 6 (f32)
+            "flops_per_launch": flops_per_launch, "launches_per_step": calls / max(n_sampled, 1),
+            # what really bounds the kernel: a chain of T dependent cross-CU hand-offs (floor measured with tools/allgather.hip)
+            "per_step_us": avg_ms * 1e3 / tavg if tavg > 0 else 0.0, "handoff_floor_us": 0.5}
+
+
+def gemm_probe(precision, reps=5):
+    """roofline_gemm: the path's three big products in the timed precision mode as STAND-ALONE whole-chip launches (outside the timed
+    region; inside the step the same kernels run beside sweeps on the XCDs those leave free and partly wait for them): HIP-event
+    average, issued bf16 MFMA rate against the 2.5 PF dense peak and against what the chip sustains on bare MFMAs."""
+    from policy_gradient_asr_amd import hipops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator().manual_seed(7)
+    M = B_PER_GPU * T
+    npl, prods = (3, 6) if precision == "f32" else (2, 3)
+
+    def timeit(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+
+    out = {}
+    pmc = {}
+    try:       # optional evidence written by tools/profile_round4.sh (never required to run)
+        with open(os.path.join(ROOT, "profiles", "r04_gemm_pmc.json")) as fi:
+            pmc = json.load(fi)
+    except Exception:  # noqa: BLE001
+        pmc = {}
+    with hipops.precision(precision):
+        for role, (N, K) in (("input_projection", (2048, 512)), ("input_gradient", (512, 2048))):
+            A = torch.randn(M, K, generator=g).to(dev)
+            W = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+            C = torch.empty(M, N, device=dev)
+            planes = hipops.split_planes(W, planes=npl)
+            us = timeit(lambda: hipops.gemm_x3w(A, planes, C, M, N, K))
+            gf = 2.0 * M * N * K / 1e9
+            name = "x6c::gemm_x6c_kernel" if npl == 3 else "c256::gemm_x3c_kernel"
+            out[role] = {"kernel": name, "shape_MNK": [M, N, K], "gflop_fp32": gf, "avg_launch_us": us,
+                         "issued_bf16_tflops": prods * gf / us * 1e3 / 1e3, "frac_of_2500": prods * gf / us / 2500.0}
+            del A, W, C, planes
+        Mw, Nw, Kw = 2048, 512, M
+        A = torch.randn(Kw, Mw, generator=g).to(dev); Bm = torch.randn(Kw, Nw, generator=g).to(dev)
+        C = torch.empty(Mw, Nw, device=dev)
+        us = timeit(lambda: hipops.gemm(A, Bm, C, Mw, Nw, Kw, transA=True, splitk=16, precision=2 if npl == 3 else 1))
+        gf = 2.0 * Mw * Nw * Kw / 1e9
+        out["weight_gradient_ih"] = {"kernel": "t6::gemm_t6_kernel" if npl == 3 else "t256::gemm_t256_kernel", "shape_MNK": [Mw, Nw, Kw],
+                                     "split_k": 16, "gflop_fp32": gf, "avg_launch_us": us,
+                                     "issued_bf16_tflops": prods * gf / us * 1e3 / 1e3, "frac_of_2500": prods * gf / us / 2500.0}
+    for rec in out.values():
+        k = rec["kernel"].split("::")[-1]
+        if k in pmc.get("kernels", {}):
+            rec["pmc_mfma_busy"] = pmc["kernels"][k].get("mfma_busy")
+            rec["pmc_source"] = pmc.get("source")
+    sustained = pmc.get("sustained_bare_mfma_tflops")
+    return {"bound": "mfma", "peak": BF16_DENSE_PEAK_TF, "unit": "TFLOP/s (issued bf16 MFMA)", "products_per_flop": prods,
+            "sustained_bare_mfma_tflops": sustained,
+            "note": "stand-alone whole-chip launches after the timed region, HIP events over %d launches; peak = 2.5 PF dense bf16; "
+                    "sustained_bare_mfma_tflops = what every CU issuing bare v_mfma_f32_32x32x16_bf16 on random operands reaches on "
+                    "this chip (tools/mfma_peak.hip, clock ~1.7-1.9 GHz under that load), from the committed profile" % reps,
+            "kernels": out}
 
 
 def allreduce_probe(trainer, dev, reps=10):
@@ -399,7 +473,9 @@ def main():
     ap.add_argument("--h2d", choices=("prefetch", "serial", "dma_prefetch", "dma_serial", "resident"), default="prefetch",
                     help="how each step's batch reaches HBM inside the timed region (resident: not at all, diagnostic)")
     ap.add_argument("--long-steps", type=int, default=200, help="second, longer timed region after the headline one (0 = off)")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the configs[4] and f32-precision legs that follow the headline")
+    ap.add_argument("--precision", choices=("f32", "bf16x3"), default="f32",
+                    help="arithmetic of the timed step: f32 = the reference's (fp32-faithful six-product kernels), bf16x3 = the faster mode within 1e-3")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the configs[4] and other-precision legs that follow the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -457,7 +533,7 @@ def main():
     model.apply(weights)
     model = model.to(dev).train()   # dropout on (model.py:45,51 p=0.5; model.py:42 p=0.3), as in training
     bucketed = args.workload == "bucketed"
-    trainer = PolicyGradientTrainer(model, lr=5e-4, lam=1.0, seed=1234, world_size=world, rank=rank,
+    trainer = PolicyGradientTrainer(model, lr=5e-4, lam=1.0, seed=1234, world_size=world, rank=rank, precision=args.precision,
                                     **({"reward_decoder": "beam", "beam_size": 16} if bucketed else {}))
     if solo_collective:
         trainer.collective = True
@@ -582,21 +658,23 @@ def main():
                         "workload": "configs[4]: beam-16 prefix-search reward hypothesis + collapse_fn + edit distance, lengths "
                                     "U[500,1000] in length-bucketed batches balanced by frames, B=32/GPU, train mode, Adam, H2D inside"}
     precision_variants, parity_batch = None, None
+    other = "bf16x3" if args.precision == "f32" else "f32"
     if world == 1 and not bucketed and not args.no_extra_legs:
-        # what the reference's own arithmetic (torch fp32) costs on this chip: the same step in precision mode "f32"
-        # (exact fp32 MFMA GEMMs, 3-plane / 6-product sweeps, no feed-ahead), outside the headline region
-        precision_variants = {"bf16x3": {"ms_per_step": (long_run or {}).get("ms_per_step", dt_local / args.steps * 1e3),
-                                         "utt_per_s": B_PER_GPU / ((long_run or {}).get("ms_per_step", dt_local / args.steps * 1e3) * 1e-3)}}
-        trainer.precision = "f32"
-        fms = timed_leg(BatchFeeder(host, dev, args.h2d, trainer), 40, 5)
-        precision_variants["f32"] = {"ms_per_step": fms, "utt_per_s": B_PER_GPU / (fms * 1e-3), "steps": 40, "warmup": 5,
-                                     "arithmetic": "every hoisted GEMM on the exact fp32 MFMA (v_mfma_f32_32x32x2_f32); recurrent sweeps on "
-                                                   "3 bf16 planes x 6 products (all terms >= 2^-24); projections before their sweeps"}
+        # the same step in the OTHER precision mode, outside the headline region (f32 = the reference's own arithmetic, torch fp32;
+        # bf16x3 = two planes / three products, within north_star's 1e-3 bar)
+        head_ms = (long_run or {}).get("ms_per_step", dt_local / args.steps * 1e3)
+        precision_variants = {args.precision: {"ms_per_step": head_ms, "utt_per_s": B_PER_GPU / (head_ms * 1e-3), "timed_as": "headline (long_run)"}}
+        trainer.precision = other
+        oms = timed_leg(BatchFeeder(host, dev, args.h2d, trainer), 40, 5)
+        precision_variants[other] = {"ms_per_step": oms, "utt_per_s": B_PER_GPU / (oms * 1e-3), "steps": 40, "warmup": 5}
+        precision_variants["f32"]["arithmetic"] = ("every big product (recurrent sweeps, W_ih projections, input / weight gradients) = six bf16 MFMA terms of a "
+                                                   "3-plane split (all terms >= 2^-24), fed + streamed orders; small products on the exact fp32 MFMA")
+        precision_variants["bf16x3"]["arithmetic"] = "every dense product = three bf16 MFMA terms of a 2-plane split (input affine on the exact fp32 MFMA)"
         if not args.no_parity:
             parity_batch = [t.to(dev) for t in host[0]]
-            with hipops.precision("f32"):
-                precision_variants["f32"]["max_rel_err_vs_fp64"] = parity_vs_fp64(model, trainer, parity_batch, brief=True)
-        trainer.precision = None
+            with hipops.precision(other):
+                precision_variants[other]["max_rel_err_vs_fp64"] = parity_vs_fp64(model, trainer, parity_batch, brief=True)
+        trainer.precision = args.precision
     dt = dt_local
     per_rank_ms = [dt_local / args.steps * 1e3]
     ar = None
@@ -613,17 +691,18 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = B_PER_GPU * world * args.steps / dt
-        rl = sweep_roofline(prof, n_sampled, sum(frames) / len(frames))
+        prods = PRODUCTS[args.precision]
+        rl = sweep_roofline(prof, n_sampled, sum(frames) / len(frames), products=prods)
         name, avg_ms, achieved, peak, flops_per_launch = rl["kernel"], rl["avg_launch_ms"], rl["achieved"], rl["peak"], rl["flops_per_launch"]
         traffic, traffic_src = None, None         # HBM bytes per launch of that kernel from the committed PMC passes
-        try:       # written by tools/pmc_summary3.py; the file is optional evidence, never required to run
-            with open(os.path.join(ROOT, "profiles", "r03_pmc.json")) as fi:
-                rec = json.load(fi)["fed_sweeps"]["kernels"][name]
+        try:       # written by tools/pmc_summary4.py; the file is optional evidence, never required to run
+            with open(os.path.join(ROOT, "profiles", "r04_pmc.json")) as fi:
+                rec = json.load(fi)[args.precision]["kernels"][name]
             traffic = rec["hbm_bytes_per_launch"]
-            traffic_src = ("from_committed_profile profiles/r03_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
-                           "gfx950 FETCH x2 correction) on the FED sweep kernels of the timed step with their producer GEMM run first "
-                           "(a counter pass serialises kernels; tools/dev/tools_fed_sweep.py); read %.0f MB + write %.0f MB per launch "
-                           "against 262 + 392 MB (forward sweep) / 392 + 262 MB (backward sweep) algorithmic"
+            traffic_src = ("from_committed_profile profiles/r04_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
+                           "gfx950 FETCH x2 correction) on the sweep kernels of this precision mode (a counter pass serialises kernels: "
+                           "the sequential order of the same kernels); read %.0f MB + write %.0f MB per launch against 262 + 392 MB "
+                           "(forward sweep) / 392 + 262 MB (backward sweep) algorithmic"
                            % (rec["hbm_read_bytes_per_launch"] / 1e6, rec["hbm_write_bytes_per_launch"] / 1e6))
         except Exception:  # noqa: BLE001
             traffic = None
@@ -633,7 +712,7 @@ def main():
             "metric": METRIC,
             "value": value, "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE, "data": "synthetic",
+            "dtype": DTYPES[args.precision], "data": "synthetic",
             "config": {"workload": ("configs[2]+[1]: CTC + REINFORCE train step (greedy baseline, sampled path, WER-style "
                                     "edit-distance reward), B=32/GPU, T=1000, F=80, V=29, L=100, Adam" if not bucketed else
                                     "configs[4]: CTC + REINFORCE train step with the reference's reward hypothesis (prefix beam "
@@ -649,17 +728,23 @@ def main():
             "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
             "collective_backend": ("none" if world == 1 else ("gloo-rehearsal (NOT a scaling number)" if rehearse else "nccl (RCCL)")),
             "ms_per_step_per_rank": per_rank_ms,
-            "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "roofline": {"bound": "latency", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "launches_per_step": rl["launches_per_step"],
                          "algorithmic_gflop_per_launch": flops_per_launch / 1e9,
-                         "peak_note": "algorithmic fp32 flops against the bf16 dense MFMA peak / 3 (the kernel issues 3 bf16 "
-                                      "products per flop): identical to issued bf16 flops / 2500 TF",
-                         "issued_bf16_tflops": 3 * achieved, "issued_bf16_frac_of_2500": 3 * achieved / BF16_DENSE_PEAK_TF,
+                         "per_step_us": rl["per_step_us"], "handoff_floor_us": rl["handoff_floor_us"],
+                         "floor_frac": rl["handoff_floor_us"] / rl["per_step_us"] if rl["per_step_us"] > 0 else None,
+                         "peak_note": "algorithmic fp32 flops against the bf16 dense MFMA peak / %d (the kernel issues %d bf16 products "
+                                      "per flop in this precision mode): identical to issued bf16 flops / 2500 TF" % (prods, prods),
+                         "issued_bf16_tflops": prods * achieved, "issued_bf16_frac_of_2500": prods * achieved / BF16_DENSE_PEAK_TF,
                          "frac_vs_fp32_mfma_peak_157.3": achieved / FP32_MFMA_PEAK_TF,
-                         "note": "serial chain of T dependent cross-CU hand-offs: latency bound, see DESIGN.md"},
+                         "note": "bound = latency: a serial chain of T dependent cross-CU hand-offs -- neither the MFMA nor the HBM roofline "
+                                 "binds; floor_frac = the measured hand-off floor of this chip (0.5 us for the 16-way all-gather, "
+                                 "tools/allgather.hip) / the per-step time: the fraction that says how close the chain is to its bound; "
+                                 "frac is kept for continuity.  The MFMA-bound kernels of the step have their fractions in roofline_gemm"},
+            "roofline_gemm": gemm_probe(args.precision) if (world == 1 and not args.no_extra_legs) else None,
             "roofline_step": {"algorithmic_tflops": step_tf, "gflop_per_step_per_gpu": gflop_step_gpu,
-                              "frac_vs_bf16x3_peak_833": step_tf / peak, "frac_vs_fp32_mfma_peak_157.3": step_tf / FP32_MFMA_PEAK_TF,
+                              "frac_vs_bf16_peak_over_products": step_tf / peak, "frac_vs_fp32_mfma_peak_157.3": step_tf / FP32_MFMA_PEAK_TF,
                               "note": "whole-step dense contraction flops (SURVEY §8d: 28.65 GFLOP per 1000-frame utterance) per GPU / ms_per_step"},
             "kernel_ms_per_step": {k: v[0] / max(n_sampled, 1) for k, v in prof.items()},
             "event_timed_steps": n_sampled,
@@ -676,10 +761,11 @@ def main():
         if bucketed_leg is not None:
             out["bucketed"] = bucketed_leg
         if world == 1 and not args.no_parity:
-            out["max_rel_err_vs_fp64"] = parity_vs_fp64(model, trainer, parity_batch if parity_batch is not None else [t.to(dev) for t in host[0]])
+            with hipops.precision(args.precision):
+                out["max_rel_err_vs_fp64"] = parity_vs_fp64(model, trainer, parity_batch if parity_batch is not None else [t.to(dev) for t in host[0]])
         if precision_variants is not None:
             if "max_rel_err_vs_fp64" in out:
-                precision_variants["bf16x3"]["max_rel_err_vs_fp64"] = {k: out["max_rel_err_vs_fp64"][k] for k in
+                precision_variants[args.precision]["max_rel_err_vs_fp64"] = {k: out["max_rel_err_vs_fp64"][k] for k in
                                                                          ("loss", "param_grads_maxnorm", "param_grads_maxnorm_tensor", "param_grads_frobenius")}
             out["precision_variants"] = precision_variants
         if world == 1 and not args.no_cpu_baseline:

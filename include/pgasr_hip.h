@@ -468,6 +468,9 @@ int pgasr_feat_power(const float* spec, long long rows, float* power, void* stre
 int pgasr_feat_db(float* mel, const int32_t* n_frames, int B, int Tmax, int n_mels, float top_db, void* stream);
 int pgasr_feat_deltas_stack(const float* mfcc, const int32_t* n_frames, int B, int Tmax, int n_mfcc,
                             float* feat, float* fmask, void* stream);
+/* x (B x Tmax x C) -> feat (B x C x Tmax), 0 past n_frames[b], and fmask (B x 1 x Tmax): the layout of data.py:64-79 for a front
+ * end without deltas -- the 80-band log-mel features (F = 80 of the benchmark; features.LogMel). */
+int pgasr_feat_stack(const float* x, const int32_t* n_frames, int B, int Tmax, int C, float* feat, float* fmask, void* stream);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,26 @@ def mfcc_deltas(wave):
     return np.concatenate((mfcc, d1, d2), axis=0)
 
 
+def log_mel(wave, n_mels=80):
+    """1-D waveform -> (n_mels, T) float64: the dB-scaled mel spectrogram the MFCC chain computes in front of its DCT, with an
+    n_mels-band HTK bank (the build's 80-band F = 80 front end, features.LogMel; not a reference call site)."""
+    p = power_spectrogram(wave)
+    mel = p @ mel_filterbank(n_mels=n_mels)
+    db = 10.0 * np.log10(np.maximum(mel, AMIN))
+    return np.maximum(db, db.max() - TOP_DB).T
+
+
+def extract_logmel(waves, n_mels=80):
+    feats = [log_mel(w, n_mels) for w in waves]
+    tmax = max(f.shape[1] for f in feats)
+    out = np.zeros((len(feats), n_mels, tmax))
+    mask = np.zeros((len(feats), 1, tmax))
+    for i, f in enumerate(feats):
+        out[i, :, :f.shape[1]] = f
+        mask[i, 0, :f.shape[1]] = 1.0
+    return out, mask
+
+
 def extract_feats(waves):
     """list of waveforms -> (B,120,Tmax) zero padded, (B,1,Tmax) masks (data.py:64-79)."""
     feats = [mfcc_deltas(w) for w in waves]

@@ -64,6 +64,7 @@ SIGNATURES = {
     "pgasr_feat_power": (C.c_int, [c_f32p, C.c_longlong, c_f32p, c_ptr]),
     "pgasr_feat_db": (C.c_int, [c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_float, c_ptr]),
     "pgasr_feat_deltas_stack": (C.c_int, [c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_ptr]),
+    "pgasr_feat_stack": (C.c_int, [c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_ptr]),
     "pgasr_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "pgasr_colsum_f32": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int,
                                    c_ptr, C.c_size_t, c_ptr]),

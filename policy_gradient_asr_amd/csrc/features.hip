@@ -89,7 +89,26 @@ __global__ __launch_bounds__(256) void feat_deltas_kernel(const float* __restric
     out[(size_t)(2 * C + c) * Tmax + t] = (-2.f * D1(t - 2) - D1(t - 1) + D1(t + 1) + 2.f * D1(t + 2)) / 10.f;
 }
 
+// x (B, Tmax, C) -> feat (B, C, Tmax) (time contiguous, 0 past the length), mask (B,1,Tmax): the layout step of a front end WITHOUT
+// deltas (the 80-band log-mel features of the benchmark's F = 80)
+__global__ __launch_bounds__(256) void feat_stack_kernel(const float* __restrict__ x, const int32_t* __restrict__ n_frames,
+                                                         int Tmax, int C, float* __restrict__ feat, float* __restrict__ fmask) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (t >= Tmax) return;
+    const int T = n_frames[b];
+    if (c == 0 && fmask) fmask[(size_t)b * Tmax + t] = t < T ? 1.f : 0.f;
+    feat[((size_t)b * C + c) * Tmax + t] = t < T ? x[((size_t)b * Tmax + t) * C + c] : 0.f;
+}
+
 }  // namespace
+
+extern "C" int pgasr_feat_stack(const float* x, const int32_t* n_frames, int B, int Tmax, int C, float* feat, float* fmask, void* stream) {
+    if (!x || !n_frames || !feat || B <= 0 || Tmax <= 0 || C <= 0 || C > 65535 || B > 65535) return PGASR_ERR_INVALID_ARG;
+    PGASR_LAUNCH_KERNEL(feat_stack_kernel, dim3((Tmax + 255) / 256, C, B), dim3(256), 0, (hipStream_t)stream, x, n_frames, Tmax, C, feat, fmask);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
 
 extern "C" int pgasr_feat_frames(const float* wave, const int32_t* n_samples, const int32_t* n_frames, int B,
                                  long long wave_stride, int Tmax, float* frames, void* stream) {

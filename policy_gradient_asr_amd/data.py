@@ -26,16 +26,19 @@ def pad_feats(feats):
 _front_end = {}
 
 
-def extract_feats(batch, device="cuda:0"):
+def extract_feats(batch, device="cuda:0", features="mfcc", keep_on_device=False):
     """data.py:44-79: MFCC(40) + delta + delta-delta per utterance, zero padded to (B,120,Tmax) + (B,1,Tmax) masks.
     An item carries precomputed features ("feat", (F,T)), a waveform tensor ("wave"), or a path ("aud", read with
-    torchaudio where it exists, else as RIFF WAV).  Waveforms go through the GPU front end (features.MFCCDeltas);
-    the result is returned on the CPU like the reference's collate output."""
+    torchaudio where it exists, else as RIFF WAV).  Waveforms go through the GPU front end: ``features`` = "mfcc"
+    (features.MFCCDeltas, the reference's 120 features) or "logmel80" (features.LogMel(80): the benchmark's F = 80).
+    keep_on_device: return the tensors where the front end left them (no host round trip on the way to the trainer);
+    default: on the CPU like the reference's collate output."""
     if all("feat" in inst for inst in batch):
-        return pad_feats([inst["feat"] for inst in batch])
+        feat, fmask = pad_feats([inst["feat"] for inst in batch])
+        return (feat.to(device), fmask.to(device)) if keep_on_device else (feat, fmask)
     if any("feat" in inst for inst in batch):
         raise ValueError("a batch mixes precomputed features and waveforms")
-    from .features import MFCCDeltas, read_wav
+    from .features import LogMel, MFCCDeltas, read_wav
     waves = []
     for inst in batch:
         if "wave" in inst:
@@ -47,11 +50,13 @@ def extract_feats(batch, device="cuda:0"):
             waves.append(waveform[0])
         except ImportError:
             waves.append(read_wav(inst["aud"])[0])
-    fe = _front_end.get(device)
+    if features not in ("mfcc", "logmel80"):
+        raise ValueError('features must be "mfcc" or "logmel80"')
+    fe = _front_end.get((str(device), features))
     if fe is None:
-        fe = _front_end[device] = MFCCDeltas(device)
+        fe = _front_end[(str(device), features)] = MFCCDeltas(device) if features == "mfcc" else LogMel(80, device)
     feat, fmask = fe(waves)
-    return feat.cpu(), fmask.cpu()
+    return (feat, fmask) if keep_on_device else (feat.cpu(), fmask.cpu())
 
 
 def encode_trans(batch):
@@ -63,9 +68,16 @@ def encode_trans(batch):
     return out, (out > 0).to(torch.int64)
 
 
-def collate_custom(batch):
-    feats, fmasks = extract_feats(batch)
-    trans, tmasks = encode_trans(batch)
+def collate_custom(batch, device=None, features="mfcc"):
+    """data.py:107-116.  device = None: the reference's contract -- everything on the CPU.  device = a GPU: "feat" / "fmask" stay
+    where the front end computed them and "trans" / "tmask" are put beside them, so ``PolicyGradientTrainer.step`` consumes the
+    batch without the features ever visiting the host (use ``functools.partial(collate_custom, device=...)`` as collate_fn)."""
+    if device is None:
+        feats, fmasks = extract_feats(batch, features=features)
+        trans, tmasks = encode_trans(batch)
+    else:
+        feats, fmasks = extract_feats(batch, device=device, features=features, keep_on_device=True)
+        trans, tmasks = (t.to(device) for t in encode_trans(batch))
     return {"feat": feats, "fmask": fmasks, "trans": trans, "tmask": tmasks}
 
 

@@ -1,5 +1,7 @@
 """Feature front end of the reference on the GPU (data.py:44-79).
 
+``LogMel(80)(waves)`` is the same front end stopped in front of the DCT with an 80-band HTK mel bank: (B,80,Tmax) dB-scaled
+log-mel features -- the "mel-spectrogram" input (F = 80) the benchmark's shapes are quoted on; feat / fmask stay on the device.
 ``MFCCDeltas()(waves)`` returns what ``extract_feats`` returns there: ``feat`` (B,120,Tmax) fp32 zero padded and
 ``fmask`` (B,1,Tmax) -- MFCC(40) + delta + delta-delta with torchaudio's default parameters, which the reference
 uses unchanged (``torchaudio.transforms.MFCC()``, ``ComputeDeltas()``).  torchaudio itself is not needed: framing,
@@ -15,8 +17,9 @@ SAMPLE_RATE, N_FFT, HOP, N_MELS, N_MFCC, TOP_DB = 16000, 400, 200, 128, 40, 80.0
 N_BINS = N_FFT // 2 + 1
 
 
-def _constants(device):
-    """DFT basis (400, 402) = [cos | -sin], HTK mel bank (201, 128), orthonormal DCT-II (128, 40); built in fp64."""
+def _constants(device, n_mels=N_MELS):
+    """DFT basis (400, 402) = [cos | -sin], HTK mel bank (201, n_mels), orthonormal DCT-II (n_mels, 40); built in fp64."""
+    N_MELS = n_mels
     n = torch.arange(N_FFT, dtype=torch.float64)[:, None]
     k = torch.arange(N_BINS, dtype=torch.float64)[None, :]
     ang = 2.0 * math.pi * n * k / N_FFT
@@ -36,16 +39,17 @@ def _constants(device):
     return tuple(t.to(torch.float32).contiguous().to(device) for t in (dft, fb, dct.t()))
 
 
-class MFCCDeltas:
-    """waves: list of 1-D float tensors (any device; moved to ``device``) -> (feat (B,120,Tmax), fmask (B,1,Tmax))."""
+class _FrontEnd:
+    """Shared part: waveforms -> dB-scaled mel spectrogram rows (B * Tmax, n_mels) on the device."""
 
-    def __init__(self, device="cuda:0"):
+    def __init__(self, device="cuda:0", n_mels=N_MELS):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.PgasrError("the feature front end runs on the MI355X only; there is no CPU path")
-        self.dft, self.fb, self.dct = _constants(self.device)
+        self.n_mels = int(n_mels)
+        self.dft, self.fb, self.dct = _constants(self.device, self.n_mels)
 
-    def __call__(self, waves):
+    def mel_db(self, waves):
         lib = _lib.load()
         dev = self.device
         B = len(waves)
@@ -69,15 +73,48 @@ class MFCCDeltas:
         hipops.gemm(frames, self.dft, spec, M=rows, N=2 * N_BINS, K=N_FFT, precision=0)
         power = torch.empty(rows, N_BINS, dtype=torch.float32, device=dev)
         _lib.check(lib.pgasr_feat_power(spec.data_ptr(), rows, power.data_ptr(), st), "pgasr_feat_power")
-        mel = torch.empty(rows, N_MELS, dtype=torch.float32, device=dev)
-        hipops.gemm(power, self.fb, mel, M=rows, N=N_MELS, K=N_BINS, precision=0)
-        _lib.check(lib.pgasr_feat_db(mel.data_ptr(), n_frames.data_ptr(), B, Tmax, N_MELS, TOP_DB, st), "pgasr_feat_db")
+        mel = torch.empty(rows, self.n_mels, dtype=torch.float32, device=dev)
+        hipops.gemm(power, self.fb, mel, M=rows, N=self.n_mels, K=N_BINS, precision=0)
+        _lib.check(lib.pgasr_feat_db(mel.data_ptr(), n_frames.data_ptr(), B, Tmax, self.n_mels, TOP_DB, st), "pgasr_feat_db")
+        return mel, n_frames, B, Tmax
+
+
+class MFCCDeltas(_FrontEnd):
+    """waves: list of 1-D float tensors (any device; moved to ``device``) -> (feat (B,120,Tmax), fmask (B,1,Tmax))."""
+
+    def __init__(self, device="cuda:0"):
+        super().__init__(device, N_MELS)
+
+    def __call__(self, waves):
+        lib = _lib.load()
+        dev = self.device
+        mel, n_frames, B, Tmax = self.mel_db(waves)
+        rows = B * Tmax
+        st = torch.cuda.current_stream().cuda_stream
         mfcc = torch.empty(rows, N_MFCC, dtype=torch.float32, device=dev)
         hipops.gemm(mel, self.dct, mfcc, M=rows, N=N_MFCC, K=N_MELS, precision=0)
         feat = torch.empty(B, 3 * N_MFCC, Tmax, dtype=torch.float32, device=dev)
         fmask = torch.empty(B, 1, Tmax, dtype=torch.float32, device=dev)
         _lib.check(lib.pgasr_feat_deltas_stack(mfcc.data_ptr(), n_frames.data_ptr(), B, Tmax, N_MFCC, feat.data_ptr(),
                                                fmask.data_ptr(), st), "pgasr_feat_deltas_stack")
+        return feat, fmask
+
+
+class LogMel(_FrontEnd):
+    """waves -> (feat (B,n_mels,Tmax), fmask (B,1,Tmax)) on the device: the dB-scaled mel spectrogram the MFCC chain computes in
+    front of its DCT (torchaudio's MelSpectrogram + AmplitudeToDB("power", top_db=80) defaults), with an ``n_mels``-band HTK bank --
+    80 bands give the F = 80 input of the benchmark (``Encoder(n_feats=80)``), feeding the instance norm / affine (A1-A2) directly."""
+
+    def __init__(self, n_mels=80, device="cuda:0"):
+        super().__init__(device, n_mels)
+
+    def __call__(self, waves):
+        lib = _lib.load()
+        mel, n_frames, B, Tmax = self.mel_db(waves)
+        feat = torch.empty(B, self.n_mels, Tmax, dtype=torch.float32, device=self.device)
+        fmask = torch.empty(B, 1, Tmax, dtype=torch.float32, device=self.device)
+        _lib.check(lib.pgasr_feat_stack(mel.data_ptr(), n_frames.data_ptr(), B, Tmax, self.n_mels, feat.data_ptr(), fmask.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), "pgasr_feat_stack")
         return feat, fmask
 
 

@@ -408,7 +408,7 @@ def gemm_x3w(A, planes, C, M, N, K, lda=None, ldc=None, bias=None, dact_y=None, 
         if t is not None and (not t.is_cuda or t.dtype != torch.float32):
             raise _lib.PgasrError(f"gemm_x3w operand {nm} must be a float32 GPU tensor")
     _check_planes(planes, N, K, "gemm_x3w")
-    with _timed("gemm_f32"):
+    with _timed("gemm_x6c" if len(planes) == 3 else "gemm_x3c"):
         if len(planes) == 3:
             st = lib.pgasr_gemm_x6w_f32(M, N, K, A.data_ptr(), K if lda is None else lda, *[t.data_ptr() for t in planes],
                                         C.data_ptr(), N if ldc is None else ldc, _p(bias), _p(dact_y), float(slope), _stream())
@@ -564,15 +564,17 @@ def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done, order=0, ph
             raise _lib.PgasrError("gemm_x3w_feed: the six-product feeds have no head launch")
         if ws is None:
             ws = _workspace(lib.pgasr_gemm_x6w_feed_workspace_bytes(), C.device, "x6w_feed")
-        st = lib.pgasr_gemm_x6w_feed_f32(M, N, K, A.data_ptr(), K, *[t.data_ptr() for t in planes], C.data_ptr(), N, _p(bias),
-                                         busy_ptr, tiles_done.data_ptr(), int(order), _p(ws), ws.numel(), _stream())
+        with _timed("gemm_feed_x6c"):        # on the feeding stream: the time includes what the persistent workgroups wait for the sweep
+            st = lib.pgasr_gemm_x6w_feed_f32(M, N, K, A.data_ptr(), K, *[t.data_ptr() for t in planes], C.data_ptr(), N, _p(bias),
+                                             busy_ptr, tiles_done.data_ptr(), int(order), _p(ws), ws.numel(), _stream())
         _lib.check(st, "pgasr_gemm_x6w_feed_f32")
         return C
     if ws is None:
         ws = _workspace(lib.pgasr_gemm_x3w_feed_workspace_bytes(), C.device, "x3w_feed")
-    st = lib.pgasr_gemm_x3w_feed_f32(M, N, K, A.data_ptr(), K, planes[0].data_ptr(), planes[1].data_ptr(), C.data_ptr(), N, _p(bias),
-                                     busy_ptr, tiles_done.data_ptr(), int(order), int(phase), FEED_HEAD_GROUPS if phase else 0,
-                                     _p(ws), ws.numel(), _stream())
+    with _timed("gemm_feed_x3w"):
+        st = lib.pgasr_gemm_x3w_feed_f32(M, N, K, A.data_ptr(), K, planes[0].data_ptr(), planes[1].data_ptr(), C.data_ptr(), N, _p(bias),
+                                         busy_ptr, tiles_done.data_ptr(), int(order), int(phase), FEED_HEAD_GROUPS if phase else 0,
+                                         _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_gemm_x3w_feed_f32")
     return ws if phase == 1 else C
 
@@ -642,7 +644,7 @@ def lstm_wgrads(dgates, x, out, T, B, in_dim, dwih, dwhh, busy_ptr=0, slab=None,
         off = ctypes.c_size_t(0)
         _lib.check(lib.pgasr_lstm_error_offset(B, 1, ctypes.byref(off)), "pgasr_lstm_error_offset")
         err_ptr = err_ws.data_ptr() + off.value
-    with _timed("gemm_f32"):
+    with _timed("gemm_t6" if planes == 3 else "gemm_t256"):      # streamed (slab != None): includes the waits for the sweep's slabs
         st = lib.pgasr_lstm_wgrads_streamed(_p(dgates), _p(x), _p(out), T, B, in_dim, _p(dwih), _p(dwhh), int(busy_ptr),
                                             _p(slab), err_ptr, planes, _p(ws), ws.numel(), _stream())
     _lib.check(st, "pgasr_lstm_wgrads_streamed")
@@ -684,10 +686,20 @@ def lstm_error_words(device):
 
 
 def lstm_error_word_tensors(device):
-    """The same words as int32 (1,) views (their workspaces start with the error word)."""
+    """The same words as int32 (1,) views, forward workspace first.  The word's place inside a workspace comes from the library
+    (``pgasr_lstm_error_offset``: the same call ``lstm_wgrads`` and ``lstm_check_error`` use), not from an assumption here."""
+    import ctypes
+    lib = _lib.load()
     cur = torch.cuda.current_stream().cuda_stream
-    return [ws[:4].view(torch.int32) for key, ws in _ws_cache.items()
-            if key[0].startswith("lstm") and key[1] == device and key[2] == cur][:2]
+    out = []
+    for tag, backward in (("lstm_fwd", 0), ("lstm_bwd", 1)):
+        ws = _ws_cache.get((tag, device, cur))
+        if ws is None:
+            continue
+        off = ctypes.c_size_t(0)
+        _lib.check(lib.pgasr_lstm_error_offset(1, backward, ctypes.byref(off)), "pgasr_lstm_error_offset")
+        out.append(ws[off.value:off.value + 4].view(torch.int32))
+    return out
 
 
 # ------------------------------------------------------------------------------------------

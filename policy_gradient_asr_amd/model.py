@@ -187,16 +187,21 @@ def _to_device(batch, device):
 
 
 def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset=None, dev_dataset=None,
-          n_feats=120, lam=1.0, lr=5e-4, resume=True, log_every=10, seed=0, bucket_by_length=True):
+          n_feats=120, lam=1.0, lr=5e-4, resume=True, log_every=10, seed=0, bucket_by_length=True, features="mfcc"):
     """Epoch loop of model.py:186-274 on the MI355X path: per-epoch train loss -> train_loss.npy,
     validation CTC loss -> val_losses.npy, model_best.pth / model_last.pth (state_dicts, reference
     names), plus checkpoint_last.pth (model + Adam moments + epoch) from which ``resume`` restarts
     -- the reference saves weights only.  ``train_dataset`` / ``dev_dataset`` default to the
-    reference's Data(train.tsv / dev.tsv, clips) and accept any Dataset of collate_custom items."""
+    reference's Data(train.tsv / dev.tsv, clips) and accept any Dataset of collate_custom items.
+    features: "mfcc" (the reference's 120 MFCC + delta features, n_feats=120) or "logmel80" (80-band log-mel, n_feats=80) for
+    items that carry waveforms / audio paths; the collate function leaves the features on the GPU (data.collate_custom(device=...)):
+    from the front end to the trainer they never visit the host."""
     import os
     import numpy as np
     import torch.utils.data as tud
-    from .data import Data, LengthBucketSampler, collate_custom, dataset_lengths
+    import functools
+    from .data import Data, LengthBucketSampler, dataset_lengths
+    from .data import collate_custom as _collate
     from .loss import pg_ctc_loss
     from .train_step import PolicyGradientTrainer
 
@@ -204,6 +209,7 @@ def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset
     alphabet, char2ind = _read_alphabet(os.path.join(corpus_path, "alphabet.txt"))
     dev = torch.device("cuda", device if isinstance(device, int) else 0) if not isinstance(device, torch.device) else device
     os.makedirs(model_path, exist_ok=True)
+    collate_custom = functools.partial(_collate, device=dev, features=features)
     if train_dataset is None:
         train_dataset = Data(os.path.join(corpus_path, "train.tsv"), os.path.join(corpus_path, "clips"), char2ind)
     if dev_dataset is None and os.path.exists(os.path.join(corpus_path, "dev.tsv")):

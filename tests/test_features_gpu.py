@@ -35,6 +35,44 @@ def test_mfcc_deltas_match_oracle(lengths):
         assert np.all(got[b, :, T:] == 0)
 
 
+@pytest.mark.parametrize("lengths", [[16000], [4000, 201, 12345]])
+def test_logmel80_matches_oracle_and_stays_on_device(lengths):
+    """N3: the 80-band log-mel front end (F = 80 of the benchmark) against the CPU restatement; outputs live on the GPU."""
+    from policy_gradient_asr_amd.features import LogMel
+    waves = _waves(lengths, seed=7 + len(lengths))
+    feat, fmask = LogMel(80, DEV)(waves)
+    assert feat.is_cuda and fmask.is_cuda
+    want, wmask = fr.extract_logmel([w.double().numpy() for w in waves], 80)
+    assert tuple(feat.shape) == want.shape and tuple(fmask.shape) == wmask.shape
+    np.testing.assert_array_equal(fmask.cpu().numpy(), wmask)
+    got = feat.cpu().numpy()
+    assert np.abs(got - want).max() < 2e-3, np.abs(got - want).max()
+    for b, n in enumerate(lengths):
+        assert np.all(got[b, :, 1 + n // 200:] == 0)
+
+
+def test_device_collate_feeds_the_trainer_without_a_host_copy():
+    """collate_custom(device=...) leaves feat / fmask on the GPU and a train step consumes them as they are."""
+    import functools
+    from policy_gradient_asr_amd.data import collate_custom
+    from policy_gradient_asr_amd.model import Seq2Seq, _to_device
+    from policy_gradient_asr_amd.train_step import PolicyGradientTrainer
+    waves = _waves([6000, 4500, 5200, 6100], seed=9)
+    char2ind = {"<pad>": 0, "a": 1, "b": 2, "c": 3}
+    batch = [{"wave": w, "trans": t, "charmap": char2ind} for w, t in zip(waves, ["ab", "c", "ba", "abc"])]
+    out = functools.partial(collate_custom, device=torch.device(DEV), features="logmel80")(batch)
+    assert out["feat"].is_cuda and out["fmask"].is_cuda and out["trans"].is_cuda and tuple(out["feat"].shape) == (4, 80, 31)
+    x, t, fmask, tmask = _to_device(out, torch.device(DEV))
+    assert x.data_ptr() == out["feat"].data_ptr()            # .to(device) of a resident tensor is the tensor itself
+    torch.manual_seed(0)
+    m = Seq2Seq(len(char2ind), n_feats=80).to(DEV).train()
+    tr = PolicyGradientTrainer(m, lr=1e-3, lam=1.0, seed=1)
+    loss = tr.step(x, t, fmask, tmask)
+    assert np.isfinite(float(loss))
+    cpu = collate_custom(batch, features="logmel80")           # the reference's contract: CPU tensors
+    assert not cpu["feat"].is_cuda and torch.equal(cpu["feat"], out["feat"].cpu())
+
+
 def test_silence_and_floor():
     """All-zero audio hits the 1e-10 floor everywhere (-100 dB), the top_db clamp is then inactive."""
     from policy_gradient_asr_amd.features import MFCCDeltas

@@ -246,3 +246,23 @@ def test_attention_decoder_oracle_matches_reference(golden_dir, vectors):
         assert got.shape == want.shape and np.abs(got - want).max() / np.abs(want).max() < 1e-5
     with pytest.raises(ValueError):
         attn_ref.attention_ctx(np.zeros((2, 8)), np.zeros((2, 3, 16)))
+
+
+def test_logmel80_oracle_bank_properties():
+    """The 80-band HTK bank of oracle/features_ref.log_mel (the build's F = 80 front end; no reference call site): triangles that
+    start at 0 Hz, peak in mel-equidistant order, overlap only with their neighbours; log_mel = the MFCC chain's dB spectrogram."""
+    from oracle import features_ref as fr
+    fb = fr.mel_filterbank(n_mels=80)
+    assert fb.shape == (201, 80) and np.all(fb >= 0) and fb.max() <= 1.0
+    peaks = fb.argmax(axis=0)
+    assert np.all(np.diff(peaks) >= 0) and peaks[0] >= 0 and peaks[-1] < 201
+    assert np.all((fb > 0).sum(axis=0) >= 1)
+    # partition of unity between the first and the last centre (HTK triangles without area normalisation)
+    inner = fb[peaks[0]:peaks[-1] + 1].sum(axis=1)
+    assert np.abs(inner - 1.0).max() < 1e-9
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal(3000) * 0.1
+    lm = fr.log_mel(w, 80)
+    assert lm.shape == (80, 16) and lm.max() - lm.min() <= 80.0 + 1e-9
+    p = fr.power_spectrogram(w) @ fb
+    np.testing.assert_allclose(lm.T, np.maximum(10 * np.log10(np.maximum(p, 1e-10)), (10 * np.log10(np.maximum(p, 1e-10))).max() - 80.0))

@@ -510,6 +510,64 @@ def test_two_bucket_allreduce_on_a_single_rank_rccl_group():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("collective", [False, True])
+def test_adam_guard_skips_the_update_when_a_sweep_error_word_is_set(collective):
+    """The device-side Adam guard (round-3 advice): a sweep's sticky error word is forged after a clean step; the next step must
+    leave parameters and both moments bit-unchanged and must not count for the bias correction; once the word is cleared the
+    following step applies with the bias correction of applied + 1 -- both with the rank-local guards (the sweeps' own words) and
+    with the flag that travels in word 0 of the gradient buffer through a (1-rank RCCL) all-reduce."""
+    import socket
+    import torch.distributed as dist
+    from policy_gradient_asr_amd import hipops
+    if collective:
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+        try:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        except Exception as e:  # noqa: BLE001
+            pytest.skip(f"cannot create a 1-rank RCCL group here: {e}")
+    try:
+        tr, batch = _trainer_and_batch(train=True)
+        tr.collective = collective
+        tr.step(*batch)
+        tr.step(*batch)
+        torch.cuda.synchronize()
+        assert tr.nstep == 2 and tr.applied_steps() == 2
+        words = hipops.lstm_error_word_tensors(tr.flat.device)
+        assert len(words) == 2 and all(int(w.item()) == 0 for w in words)
+        snap = [t.clone() for t in (tr.flat, tr.exp_avg, tr.exp_avg_sq)]
+        words[1].fill_(1)                               # forge: "the backward sweep gave up on a bounded wait"
+        tr.step(*batch)
+        torch.cuda.synchronize()
+        assert tr.nstep == 3 and tr.applied_steps() == 2           # the call counted, the update did not
+        for a, b in zip(snap, (tr.flat, tr.exp_avg, tr.exp_avg_sq)):
+            assert torch.equal(a[64:], b[64:])                     # bit-unchanged (the leading flag words are not state)
+        if collective:
+            assert float(tr.gflat[0]) > 0                          # the flag went through the all-reduce in word 0
+        with pytest.raises(Exception):
+            hipops.lstm_assert_no_timeouts()                       # and the host check reports it
+        for w in words:
+            w.zero_()
+        g_before = tr.exp_avg.clone()
+        tr.step(*batch)
+        torch.cuda.synchronize()
+        assert tr.nstep == 4 and tr.applied_steps() == 3
+        assert not torch.equal(g_before[64:], tr.exp_avg[64:])
+        # bias correction with the APPLIED count (3), not the call count (4): replay the update on the host
+        b1, b2, lr, eps = 0.9, 0.999, tr.lr, 1e-8
+        g = tr.gflat[64:].double().cpu()
+        m = (snap[1][64:].double().cpu() * b1 + (1 - b1) * g)
+        v = (snap[2][64:].double().cpu() * b2 + (1 - b2) * g * g)
+        want = snap[0][64:].double().cpu() - lr * (m / (1 - b1 ** 3)) / ((v / (1 - b2 ** 3)).sqrt() + eps)
+        assert rel_err(tr.flat[64:].cpu(), want) < 1e-5
+        wrong = snap[0][64:].double().cpu() - lr * (m / (1 - b1 ** 4)) / ((v / (1 - b2 ** 4)).sqrt() + eps)
+        assert float((tr.flat[64:].double().cpu() - want).abs().max()) < 0.2 * float((wrong - want).abs().max())
+    finally:
+        for w in hipops.lstm_error_word_tensors(torch.device(DEV)):
+            w.zero_()
+        if collective:
+            dist.destroy_process_group()
+
+
 def test_feed_ahead_gemms_give_identical_train_steps():
     """functional.FEED_AHEAD: input projections run beside the forward sweeps they feed, the upper layers' input-gradient
     GEMMs beside the backward sweeps they feed with the inter-layer dropout mask applied by the sweep's helper
