@@ -417,7 +417,7 @@ def gemm_probe(precision, reps=5):
             gf = 2.0 * M * N * K / 1e9
             name = "x6c::gemm_x6c_kernel" if npl == 3 else "c256::gemm_x3c_kernel"
             out[role] = {"kernel": name, "shape_MNK": [M, N, K], "gflop_fp32": gf, "avg_launch_us": us,
-                         "issued_bf16_tflops": prods * gf / us * 1e3 / 1e3, "frac_of_2500": prods * gf / us / 2500.0}
+                         "issued_bf16_tflops": prods * gf / us * 1e3, "frac_of_2500": prods * gf / us * 1e3 / BF16_DENSE_PEAK_TF}
             del A, W, C, planes
         Mw, Nw, Kw = 2048, 512, M
         A = torch.randn(Kw, Mw, generator=g).to(dev); Bm = torch.randn(Kw, Nw, generator=g).to(dev)
@@ -426,13 +426,16 @@ def gemm_probe(precision, reps=5):
         gf = 2.0 * Mw * Nw * Kw / 1e9
         out["weight_gradient_ih"] = {"kernel": "t6::gemm_t6_kernel" if npl == 3 else "t256::gemm_t256_kernel", "shape_MNK": [Mw, Nw, Kw],
                                      "split_k": 16, "gflop_fp32": gf, "avg_launch_us": us,
-                                     "issued_bf16_tflops": prods * gf / us * 1e3 / 1e3, "frac_of_2500": prods * gf / us / 2500.0}
+                                     "issued_bf16_tflops": prods * gf / us * 1e3, "frac_of_2500": prods * gf / us * 1e3 / BF16_DENSE_PEAK_TF}
     for rec in out.values():
         k = rec["kernel"].split("::")[-1]
         if k in pmc.get("kernels", {}):
             rec["pmc_mfma_busy"] = pmc["kernels"][k].get("mfma_busy")
             rec["pmc_source"] = pmc.get("source")
     sustained = pmc.get("sustained_bare_mfma_tflops")
+    if sustained:
+        for rec in out.values():
+            rec["frac_of_sustained"] = rec["issued_bf16_tflops"] / sustained
     return {"bound": "mfma", "peak": BF16_DENSE_PEAK_TF, "unit": "TFLOP/s (issued bf16 MFMA)", "products_per_flop": prods,
             "sustained_bare_mfma_tflops": sustained,
             "note": "stand-alone whole-chip launches after the timed region, HIP events over %d launches; peak = 2.5 PF dense bf16; "

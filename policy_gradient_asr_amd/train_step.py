@@ -221,7 +221,14 @@ class DataParallelStep:
 class PolicyGradientTrainer(DataParallelStep):
     """step(x, targets, fmask, tmask): x (B,F,T) fp32; targets (B,L) int (pad 0); fmask (B,T);
     tmask (B,L) -- the collate_custom batch (data.py:107-116) after model.py:227-230's squeeze.
-    Returns the detached local loss (no host sync)."""
+    Returns the detached local loss (no host sync).
+    ONE trainer steps at a time per process: the overlap / stream / held-tensor state of the host layer (functional.grad_overlap,
+    streams) is process-global and guarded by a step lock -- a second trainer may step between the steps of the first, a concurrent
+    ``step()`` raises RuntimeError.
+    Data parallel: ranks are expected to hold CONTIGUOUS shards of the global batch (``shard_slice``): the sampler addresses its draws by
+    global utterance index ``rank * local_B + b``, which makes N ranks sample exactly what one process holding the whole batch samples.
+    With ``balance_by_frames`` shards (variable lengths, configs[4]) the draws are still distinct and the training valid, but that
+    identity with the single-process run does not hold."""
 
     def __init__(self, model, lr=5e-4, lam=1.0, seed=0, blank=0, world_size=1, process_group=None, rank=0,
                  reward_decoder="greedy", beam_size=16, precision=None):

@@ -325,7 +325,9 @@ def test_pg_step_with_beam_reward_vs_oracle():
 
 def test_pg_step_full_size_lambda1_vs_oracle():
     """configs[2] as a whole step at the headline shape (B=32,T=1000,F=80,V=29,L=100), lambda = 1: rewards exact,
-    loss and every parameter gradient within 1e-3 of the CPU path."""
+    loss and every parameter gradient within 1e-3 of the CPU path.  (Where a beam reward is used, this harness cross-checks only 2 of
+    the 32 beam hypotheses against the pure-Python prefix search -- it takes minutes per utterance at T = 1000; all 32 are covered
+    by tests/test_decoders_gpu.py::test_beam_headline_size_properties.)"""
     _pg_step_vs_oracle(32, 80, 1000, 29, 100, [1000] * 32, [100] * 32, seed=31, threads=min(16, os.cpu_count() or 1),
                        share_choices=True)
 
@@ -334,7 +336,8 @@ def test_bucketed_full_size_step():
     """configs[4] as a whole step at full size: B = 32, lengths U[500,1000] (L = T/10), the reference's reward hypothesis
     (prefix beam search, beam 16 -> collapse_fn -> edit distance, policy_grad.py:6-8), eval mode; loss and every parameter
     gradient within 1e-3 of the torch-CPU model with the PACKED LSTM exactly as model.py:52-55 calls it, discrete choices
-    shared (see _pg_step_vs_oracle)."""
+    shared (see _pg_step_vs_oracle).  Only 2 of the 32 beam hypotheses are cross-checked against the pure-Python prefix search
+    here; the rest rely on tests/test_decoders_gpu.py::test_beam_headline_size_properties."""
     g = torch.Generator().manual_seed(77)
     lens = torch.randint(500, 1001, (32,), generator=g).tolist()
     lens[5] = 1000                                       # Tmax is reached
