@@ -765,7 +765,16 @@ static int x6_var() {       // PGASR_X6_VAR (read at every call: A/B inside one 
     return (e && e[0] == '0') ? 0 : 7;
 }
 constexpr int X6_FEED_SPLIT_MAX = 32;      // split tiles per feed: 4 x 32 slabs of 256 KB = 32 MB of workspace
-int x6_quarters(int K) { return (K >= 1024 && K % (4 * x6c::TK) == 0) ? 4 : 1; }
+// K in quarters for the first tiles of a feed (K >= 1024: the input-gradient feeds).  The K = 512 projections in quarters were measured
+// (round 4, PGASR_X6_QUARTER_K=512, same box, 2 x 40 steps each): forward sweeps 1.54 against 1.47 ms, step 10.67-10.70 against
+// 10.45-10.53 -- four items, a parked accumulator set and a reduction per tile cost the feed more than the first rows gain; the
+// bf16x3 feeds had found the same.  The switch stays for A/B only: below 1024 the fed and the sequential order of a FORWARD
+// projection no longer give the same bits (the sequential order runs the one-chain kernel).
+int x6_quarters(int K) {
+    const char* e = getenv("PGASR_X6_QUARTER_K");
+    const int kmin = e ? atoi(e) : 1024;
+    return (K >= kmin && K >= 16 * x6c::TK && K % (4 * x6c::TK) == 0) ? 4 : 1;
+}
 
 }  // namespace
 
