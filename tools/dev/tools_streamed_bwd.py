@@ -16,6 +16,7 @@ params = []
 for d in range(2):
     params += [torch.randn(4 * H, I, generator=g) * 0.05, (torch.rand(4 * H, H, generator=g) * 2 - 1) / 16, torch.zeros(4 * H), torch.zeros(4 * H)]
 params = [p.to(dev) for p in params]
+hipops.set_precision(os.environ.get("PREC", "bf16x3"))      # "f32": three-plane sweep, six-product weight gradients
 wih, bias, pf, pb = hipops.lstm_pack(params, I)
 x = torch.randn(T, B, I, generator=g).to(dev)
 dy = (torch.randn(T, B, I, generator=g) * 1e-2).to(dev)
