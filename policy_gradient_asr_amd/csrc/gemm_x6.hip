@@ -130,8 +130,8 @@ __device__ __forceinline__ void mfma6(f32x16 (&acc)[2], const u32x4_t (&a)[3], c
 // cycles, whatever the priorities), so a "memory phase beside a multiply phase" does not overlap -- with the k-loop's pieces switched
 // off in turn, MFMA + fragment reads alone took 322 us, everything but the MFMAs 180 us, together 410: they ADD.  And a whole
 // chip of bare v_mfma_f32_32x32x16_bf16 on random operands sustains 1.7-1.9 PF at 1.7-1.86 GHz (tools/mfma_peak.hip), not 2.5.
-// A ONE-wave-per-SIMD form of VAR 7 (four waves x 128 x 128, 256 accumulators in AGPRs, ~2 fillers per MFMA gap; commit "x6q" in the
-// history) was built too: correct, bit-identical, 403 / 376 us against 420 / 382 -- 3 %, and its FEED form spilled; not kept.  What a
+// A ONE-wave-per-SIMD form of VAR 7 (four waves x 128 x 128, 256 accumulators in AGPRs, ~2 fillers per MFMA gap; NOTES.md 1.3, not in the
+// tree) was built too: correct, bit-identical, 403 / 376 us against 420 / 382 -- 3 %, and its FEED form spilled; not kept.  What a
 // filler costs beside back-to-back MFMAs with nobody else on the SIMD is in profiles/r04_mfma_filler.txt (tools/mfma_filler.hip):
 // VALU up to ~4 per gap nearly free (32.7 -> 35 cycles per MFMA), but one ds_read_b128 per gap +9 cycles and LDS writes far more --
 // the LDS pipe, not the issue port, is what the fragment reads and plane stores of these kernels pay for.
