@@ -106,11 +106,19 @@ extern "C" int pgasr_edit_distance(const int32_t* ref, const int32_t* ref_len, i
     // too: two chains on one SIMD slow each other, and both kernels are as slow as their slowest workgroup.  Up to 128 pairs (the
     // step's 2 B) each get an LDS reservation nobody else leaves room for, i.e. an idle CU of their own (loss section 0.48 ->
     // 0.45 ms, step -0.04 ms; PGASR_ED_LDS=0 switches it off); bulk calls keep many waves per CU.
-    static const int ed_env = [] { const char* e = getenv("PGASR_ED_LDS"); return e ? atoi(e) : 156 * 1024; }();
-    const int ed_lds = N <= 128 ? ed_env : 0;
+    static const int ed_env = [] {
+        const char* e = getenv("PGASR_ED_LDS");
+        int want = e ? atoi(e) : 156 * 1024, dev = 0, cap = 0;
+        // never ask for more than the device gives one workgroup (round-3 advice: a smaller-LDS part would fail every small call)
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && cap > 0 && want > cap)
+            want = cap;
+        return want > 0 ? want : 0;
+    }();
+    int ed_lds = N <= 128 ? ed_env : 0;
 #define ED_LAUNCH(JJ)                                                                             \
-    do { if (ed_lds > 0) (void)hipFuncSetAttribute((const void*)edit_distance_kernel<JJ>, hipFuncAttributeMaxDynamicSharedMemorySize, ed_lds); \
-    PGASR_LAUNCH_KERNEL(edit_distance_kernel<JJ>, dim3(N), dim3(64), (size_t)(ed_lds > 0 ? ed_lds : 0), st, ref, ref_len,          \
+    do { if (ed_lds > 0 && hipFuncSetAttribute((const void*)edit_distance_kernel<JJ>, hipFuncAttributeMaxDynamicSharedMemorySize, ed_lds) != hipSuccess) \
+             ed_lds = 0;                  /* no reservation rather than a failed launch: the pairs then share CUs (slower beside a lattice, never wrong) */ \
+    PGASR_LAUNCH_KERNEL(edit_distance_kernel<JJ>, dim3(N), dim3(64), (size_t)ed_lds, st, ref, ref_len,          \
                        ref_stride, hyp, hyp_len, hyp_stride, dist, prefix_dist); } while (0)
     if (need <= 1) ED_LAUNCH(1);
     else if (need <= 2) ED_LAUNCH(2);

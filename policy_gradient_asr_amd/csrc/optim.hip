@@ -128,7 +128,13 @@ extern "C" int pgasr_stream_copy(const void* src, void* dst, unsigned long long 
     // The copy's workgroups must not share a CU with anybody's dependent chain (a sweep member, a lattice workgroup): a CU that
     // also serves eight 16-byte host reads per lane slows its other tenant, and a sweep is as slow as its slowest member.  An LDS
     // reservation nobody else leaves room for makes the dispatcher pick an otherwise idle CU (PGASR_COPY_LDS=0: no reservation).
-    static const int copy_lds = [] { const char* e = getenv("PGASR_COPY_LDS"); return e ? atoi(e) : 156 * 1024; }();
+    static const int copy_lds = [] {
+        const char* e = getenv("PGASR_COPY_LDS");
+        int want = e ? atoi(e) : 156 * 1024, dev = 0, cap = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && cap > 0 && want > cap)
+            want = cap;          // never more than the device gives one workgroup
+        return want > 0 ? want : 0;
+    }();
     if (copy_lds > 0 && hipFuncSetAttribute((const void*)stream_copy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, copy_lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
     PGASR_LAUNCH_KERNEL(stream_copy_kernel, dim3(workgroups), dim3(256), (size_t)(copy_lds > 0 ? copy_lds : 0), (hipStream_t)stream, (const v4u*)src, (v4u*)dst, n16,

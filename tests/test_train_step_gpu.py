@@ -571,10 +571,12 @@ def test_adam_guard_skips_the_update_when_a_sweep_error_word_is_set(collective):
             dist.destroy_process_group()
 
 
-def test_feed_ahead_gemms_give_identical_train_steps():
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_feed_ahead_gemms_give_identical_train_steps(mode):
     """functional.FEED_AHEAD: input projections run beside the forward sweeps they feed, the upper layers' input-gradient
     GEMMs beside the backward sweeps they feed with the inter-layer dropout mask applied by the sweep's helper
-    workgroups.  Train mode (dropout on): gradients and parameters equal the sequential order bit for bit."""
+    workgroups.  Train mode (dropout on): gradients and parameters equal the sequential order bit for bit -- in both precision
+    modes (f32: the six-product feeds of gemm_x6.hip beside three-plane sweeps)."""
     from policy_gradient_asr_amd import functional as Fh
     prev = Fh.FEED_AHEAD
     res = []
@@ -582,6 +584,7 @@ def test_feed_ahead_gemms_give_identical_train_steps():
         for feed in (False, True):
             Fh.FEED_AHEAD = feed
             tr, batch = _trainer_and_batch(train=True)
+            tr.precision = mode
             tr.step(*batch)
             torch.cuda.synchronize()
             g1 = tr.gflat.clone()
@@ -595,7 +598,8 @@ def test_feed_ahead_gemms_give_identical_train_steps():
     assert float(res[0][0].abs().sum()) > 0
 
 
-def test_streamed_weight_gradients_give_identical_train_steps():
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_streamed_weight_gradients_give_identical_train_steps(mode):
     """functional.STREAM_DW: every BLSTM layer's weight-gradient products run beside that layer's OWN backward sweep and consume
     its dgates slab by slab (pgasr_lstm_layer_bwd_streamed / pgasr_lstm_wgrads_streamed).  Gradients and parameters equal, bit for
     bit, those of the order in which the products wait for the sweep's end, with and without the overlap machinery."""
@@ -607,6 +611,7 @@ def test_streamed_weight_gradients_give_identical_train_steps():
         for stream_dw, overlap in ((False, True), (True, True), (True, True), (False, False)):
             Fh.STREAM_DW = stream_dw
             tr, batch = _trainer_and_batch(train=True, B=32, T=200)
+            tr.precision = mode
             tr.overlap_weight_grads = overlap
             tr.step(*batch)
             torch.cuda.synchronize()
