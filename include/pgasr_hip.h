@@ -338,6 +338,9 @@ int pgasr_lstm_error_offset(int B, int backward, size_t* offset);
  * set (PGASR_OK otherwise); pgasr_adam_step takes the words' device addresses as guards and skips the update while
  * one is set, so invalid gradients never reach the parameters between two host-side checks. */
 int pgasr_lstm_status(const void* workspace, size_t workspace_bytes, int B, int backward, void* stream);
+/* out[0] = 1.0f if *word0 or *word1 (sweep error words; either may be NULL) is non-zero, else 0.0f -- the flag a data-parallel rank writes
+ * into word 0 of its gradient buffer before the last all-reduce, so that every replica skips the Adam update together (one launch). */
+int pgasr_error_flag(const int32_t* word0, const int32_t* word1, float* out, void* stream);
 int pgasr_lstm_busy_offset(int B, int backward, size_t* offset);   /* 8 per-XCD busy counters (hint for pgasr_gemm_f32) */
 /* Holds `stream` until any of words[0..count) is non-zero or timeout_us (<= 100000) has passed: put in front of
  * GEMMs that are to run BESIDE a sweep, so that the sweep's workgroups are dispatched first (a large grid

@@ -157,6 +157,18 @@ extern "C" int pgasr_dropout(const float* x, float* y, unsigned long long n, flo
     return PGASR_OK;
 }
 
+// out[0] = 1.0f if one of the (up to two) sweep error words is set, else 0.0f: the flag a rank puts into word 0 of its gradient buffer
+// before the last bucket's all-reduce (train_step.DataParallelStep) -- one launch instead of four tiny tensor ops on the critical stream
+namespace { __global__ void error_flag_kernel(const int* w0, const int* w1, float* out) {
+    if (threadIdx.x == 0) out[0] = ((w0 && *w0 != 0) || (w1 && *w1 != 0)) ? 1.f : 0.f;
+} }
+extern "C" int pgasr_error_flag(const int32_t* word0, const int32_t* word1, float* out, void* stream) {
+    if (!out) return PGASR_ERR_INVALID_ARG;
+    PGASR_LAUNCH_KERNEL(error_flag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int*)word0, (const int*)word1, out);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
+
 extern "C" int pgasr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, unsigned long long n,
                                int step, float lr, float beta1, float beta2, float eps, float weight_decay,
                                const int32_t* guard0, const int32_t* guard1, int32_t* applied, void* stream) {

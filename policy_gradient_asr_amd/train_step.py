@@ -142,19 +142,20 @@ class DataParallelStep:
     def forward_loss(self, batch, global_batch):  # pragma: no cover - abstract
         raise NotImplementedError
 
-    def local_error_flag(self):
-        """0-d / 1-element fp32 tensor on the gradients' device: > 0 iff THIS rank's step produced invalid gradients (a
-        persistent sweep gave up on a bounded wait; the words are sticky).  None: nothing to report (CPU plumbing)."""
+    def write_local_error_flag(self):
+        """Word 0 of the gradient buffer := 1.0 iff THIS rank's step produced invalid gradients (a persistent sweep gave up on a bounded
+        wait; the words are sticky), else 0.0 -- one small launch on the current stream (``pgasr_error_flag``).  Returns False where
+        there is nothing to report (CPU plumbing, no sweep workspace yet)."""
         if not self.flat.is_cuda:
-            return None
-        from . import hipops
+            return False
+        from . import _lib, hipops
         words = hipops.lstm_error_word_tensors(self.flat.device)
         if not words:
-            return None
-        flag = words[0].ne(0)
-        for w in words[1:]:
-            flag = flag | w.ne(0)
-        return flag.to(torch.float32)
+            return False
+        lib = _lib.load()
+        _lib.check(lib.pgasr_error_flag(words[0].data_ptr(), words[1].data_ptr() if len(words) > 1 else None, self.gflat.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), "pgasr_error_flag")
+        return True
 
     def applied_steps(self):
         """Number of Adam updates really applied (synchronises): ``nstep`` minus the updates the guard skipped."""
@@ -197,9 +198,7 @@ class DataParallelStep:
         if self.collective:
             # the error flag travels with the last gradient bucket (word 0, see FLAG_PAD): SUM > 0 on every rank iff any
             # rank's gradients are invalid
-            flag = self.local_error_flag()
-            if flag is not None:
-                self.gflat[0:1].copy_(flag.reshape(1))
+            self.write_local_error_flag()
         self.reduce_rest()
         self.nstep += 1
         if self.opt is None:

@@ -34,9 +34,10 @@ class ToyStepOneRankFails(ToyStepTwoBuckets):
     the gradient all-reduce, so that both replicas skip that update together."""
     fail_rank, fail_call = 1, 1
 
-    def local_error_flag(self):
+    def write_local_error_flag(self):
         bad = dist.get_rank() == self.fail_rank and self.nstep == self.fail_call
-        return torch.tensor(1.0 if bad else 0.0)
+        self.gflat[0] = 1.0 if bad else 0.0          # what pgasr_error_flag writes on the device
+        return True
 
 
 def make_model():
