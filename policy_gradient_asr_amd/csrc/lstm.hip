@@ -42,11 +42,16 @@ constexpr int N_HELPERS = PGASR_N_HELPERS;       // + helper workgroups per clus
 #define PGASR_FWD_RING_STEPS 16
 #endif
 #ifndef PGASR_BWD_RING_STEPS
-#define PGASR_BWD_RING_STEPS 16
+#define PGASR_BWD_RING_STEPS 12
 #endif
-// ring depth per sweep (steps).  Stand-alone sweeps: forward 8 -> 1.15 us/step, 16 -> 1.23, 32 -> 1.33 (a smaller ring
-// stays in L2); backward 8 -> 1.71, 16 -> 1.62 (its loader runs 4 steps ahead and needs the slack).  Inside the train
-// step 8/16 and 16/16 measured the same (11.86 vs 11.82 ms), so both use 16.
+// ring depth per sweep (steps).  Stand-alone sweeps (round 1): forward 8 -> 1.15 us/step, 16 -> 1.23, 32 -> 1.33 (a smaller ring
+// stays in L2); backward 8 -> 1.71, 16 -> 1.62 (its loader runs 4 steps ahead and needs the slack).
+// Round 4: the BACKWARD ring is 12 steps.  Its slots are 96 KB (gates + c + dout), and beside the 512 KB exchange slots a 16-step ring
+// (1.5 MB per cluster) did not survive in the XCD's 4 MB L2 between its uses: every staged line was written back to HBM once -- the
+// backward sweep's WRITE_SIZE was 538-675 MB per launch against 262 MB of dgates (round 1-3 verdicts).  Same box, A/B by library
+// (tools/dev/r4_ring.sh): 16 steps 538 MB, 12 steps 287 MB, 10 steps 269 MB; stand-alone backward sweep 1.130 / 1.130 / 1.160 ms
+// (bf16x3), 1.298 / 1.287 / 1.297 (f32); f32 step 10.22 / 10.18 / 10.18 ms.  (Round 2's 8-step ring cut the traffic too but cost the
+// sweep 30 %: the helpers lose the slack that hides a slow DRAM burst; 12 keeps it.)
 constexpr int FWD_RING_STEPS = PGASR_FWD_RING_STEPS, BWD_RING_STEPS = PGASR_BWD_RING_STEPS;
 constexpr int RING_STEPS_MAX = 32;     // depth of that ring (steps)
 constexpr int FWD_STEP_FLOATS = 16 * 1024;                           // 16 utterances x (256 units x 4 gates)

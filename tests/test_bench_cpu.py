@@ -81,24 +81,46 @@ def test_roofline_record_counts_launches_per_sampled_step():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r03_bench.json is one line of `python bench.py` on an MI355X: the driver's contract fields, the roofline and CPU
-    baseline objects, and the round's extra legs are all there and consistent with each other."""
+    """profiles/r04_bench.json is one line of `python bench.py` on an MI355X (default precision f32): the driver's contract fields, the
+    roofline (latency-bound sweep with its hand-off floor), the MFMA-bound kernels' roofline_gemm, the CPU baseline and the round's extra
+    legs are all there and consistent with each other; profiles/r04_bench_bf16x3.json is the same command with --precision bf16x3."""
     import json
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "dtype", "data", "config", "roofline", "roofline_gemm", "cpu_baseline"):
         assert k in d, k
+    assert d["metric"] == bench.METRIC and d["dtype"].startswith("f32")
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6           # utterances/sec of B = 32 per GPU
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] > 0
-    assert r["launches_per_step"] == 3.0
+    assert r["bound"] == "latency" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] > 0
+    assert abs(r["peak"] - 2500.0 / 6) < 1e-9                                              # six bf16 products per flop in the f32 mode
+    assert r["launches_per_step"] == 3.0 and r["handoff_floor_us"] == 0.5
+    assert abs(r["per_step_us"] - r["avg_launch_ms"]) < 1e-9                               # T = 1000 steps per launch
+    assert abs(r["floor_frac"] - 0.5 / r["per_step_us"]) < 1e-9 and 0.2 < r["floor_frac"] < 0.6
+    g = d["roofline_gemm"]
+    assert g["bound"] == "mfma" and g["peak"] == 2500.0 and g["products_per_flop"] == 6
+    for role in ("input_projection", "input_gradient", "weight_gradient_ih"):
+        k = g["kernels"][role]
+        assert abs(k["issued_bf16_tflops"] - 6 * k["gflop_fp32"] / k["avg_launch_us"] * 1e3) < 1e-6
+        assert abs(k["frac_of_2500"] - k["issued_bf16_tflops"] / 2500.0) < 1e-9 and 0.3 < k["frac_of_2500"] < 0.8
+        assert 0.4 < k["pmc_mfma_busy"] < 1.0 and "profiles/" in k["pmc_source"]
+        assert abs(k["frac_of_sustained"] - k["issued_bf16_tflops"] / g["sustained_bare_mfma_tflops"]) < 1e-9
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     for leg in ("long_run", "inputs_resident", "bucketed", "precision_variants", "max_rel_err_vs_fp64"):
         assert leg in d, leg
     assert d["inputs_resident"]["ms_per_step"] <= d["long_run"]["ms_per_step"] * 1.02      # staging costs time, never saves it
-    assert d["max_rel_err_vs_fp64"]["param_grads_maxnorm"] < 1e-3 and d["max_rel_err_vs_fp64"]["loss"] < 1e-3
+    assert d["max_rel_err_vs_fp64"]["param_grads_frobenius"] < 1e-5 and d["max_rel_err_vs_fp64"]["loss"] < 1e-5
     pv = d["precision_variants"]
-    assert pv["f32"]["max_rel_err_vs_fp64"]["param_grads_frobenius"] < pv["bf16x3"]["max_rel_err_vs_fp64"]["param_grads_frobenius"]
+    assert pv["f32"]["max_rel_err_vs_fp64"]["param_grads_frobenius"] < pv["bf16x3"]["max_rel_err_vs_fp64"]["param_grads_frobenius"] < 1e-3
+    assert pv["f32"]["ms_per_step"] <= 11.0 and pv["bf16x3"]["ms_per_step"] < pv["f32"]["ms_per_step"]
+    b = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_bf16x3.json")))
+    assert b["dtype"].startswith("bf16x3") and abs(b["roofline"]["peak"] - 2500.0 / 3) < 1e-9 and b["roofline_gemm"]["products_per_flop"] == 3
+    assert b["ms_per_step"] < d["ms_per_step"]
+    # the N > 1 plumbing rehearsal (two ranks on ONE GPU over gloo) ran every leg with world 2 and says what it is
+    reh = json.load(open(os.path.join(ROOT, "profiles", "r04_rehearse.json")))
+    assert reh["n_gpus"] == 2 and reh["rccl_world_size"] == 2 and "NOT a scaling number" in reh["collective_backend"]
+    for leg in ("long_run", "inputs_resident", "bucketed"):
+        assert reh[leg]["ms_per_step"] > 0
