@@ -443,14 +443,14 @@ def _streamed_case(T, B, lens, flags, tol, dev):
             busy = hipops.lstm_busy_ptr(T, B, True, dev)
             if rep == 2:
                 torch.cuda.synchronize()        # a consumer that comes LATE: the sweep is over, its busy counters are back to zero --
-                t_late = time.perf_counter()    # the gate must open on the publications, not sit out its (here 1 s) time-out
+                t_late = time.perf_counter()    # the gate must open on the publications, not sit out its (here 100 ms, the entry point's maximum) time-out
             with torch.cuda.stream(side):
                 side.wait_event(before)
-                hipops.stream_gate(busy, need=2 * ((B + 15) // 16), timeout_us=1000000 if rep == 2 else 5000, running=words)
+                hipops.stream_gate(busy, need=2 * ((B + 15) // 16), timeout_us=100000 if rep == 2 else 5000, running=words)
                 hipops.lstm_wgrads(dg, xd, out, T, B, 512, dwih, dwhh, busy_ptr=busy, slab=words, err_ws=ws)
             torch.cuda.synchronize()
             if rep == 2:
-                assert time.perf_counter() - t_late < 0.5      # (a loaded box needed 86 ms for the launches once: the margin is to the time-out, not to the work)
+                assert time.perf_counter() - t_late < 0.095    # below the time-out (the work itself is ~2 ms; a loaded box once needed 86 ms of host time)
             hipops.lstm_check_error(ws, B, True)
             nc = 2 * ((B + 15) // 16)
             assert words[:nc].tolist() == [len(edges) - 1] * nc
