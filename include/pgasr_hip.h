@@ -254,6 +254,11 @@ int pgasr_lstm_wgrads_streamed(const float* dgates, const float* x, const float*
  *   fed_need of the consumer = pgasr_gemm_x6w_feed_col_tiles(N) = N / 512.  With pgasr_gemm_x6w_feed_workspace_bytes() the first
  *   tiles of a K >= 1024 (K % 64 == 0) feed are fixed-order sums ((q0 + q1) + q2) + q3 of K-quarters computed in parallel; called
  *   with xcc_busy = NULL before a plain sweep it is the sequential order of the same product with the same bits. */
+/* pgasr_pack_x6w_planes: the same three planes PACKED tile by tile in the kernel's own LDS-image order,
+ *   pack[N/256][K/16][plane 3][8 KB]  (N*K*6 bytes; N = rows, K = cols of the weight as the GEMM sees it; transpose as above),
+ * so that a W piece of a step is 1 KB of consecutive bytes (8 full cache lines per LDS-DMA instruction instead of 32 quarter lines of a
+ * row-major plane).  Needs N % 256 == 0, K % 16 == 0.  pgasr_gemm_x6w_f32 / _feed_f32 take a pack as Whi with Wmid = Wlo = NULL. */
+int pgasr_pack_x6w_planes(const float* src, int rows, int cols, int ld, int transpose, void* pack, void* stream);
 int pgasr_split_bf16_planes3(const float* src, int rows, int cols, int ld, int transpose,
                              unsigned short* hi, unsigned short* mid, unsigned short* lo, void* stream);
 int pgasr_gemm_x6w_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,

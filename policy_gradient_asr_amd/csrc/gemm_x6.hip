@@ -180,16 +180,23 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
         apw[j] = (unsigned)(r * 32 + (((ac >> 1) ^ ((r >> 3) & 1)) * 16) + (ac & 1) * 8);
     }
     // ---- W planes by LDS-DMA: piece = 32 rows x 32 B; wave w moves piece w of each plane
+    // PACKED operand (g.Wmid == nullptr; pgasr_pack_x6w_planes): W is stored tile by tile in the LDS image's own order,
+    // [column tile][16-deep step][plane][8 KB image], so a W piece is 1 KB of consecutive bytes -- 8 full lines per wave instruction
+    // instead of 32 quarter lines of a row-major plane (1,024 -> 448 TCP requests per step)
+    const bool packed = g.Wmid == nullptr;
     const unsigned short* pw[3];
     {
         const int row = 32 * w + (lane >> 1), cp = lane & 1, c = cp ^ ((row >> 3) & 1);
         const size_t o = (size_t)(n0 + row) * g.K + c * 8;
-        pw[0] = g.Whi + o; pw[1] = g.Wmid + o; pw[2] = g.Wlo + o;
+        pw[0] = g.Whi + o; pw[1] = packed ? g.Whi : g.Wmid + o; pw[2] = g.Wlo + o;
     }
+    const unsigned char* wpk = reinterpret_cast<const unsigned char*>(g.Whi) + (size_t)tbx * nk * WSTAGE_BYTES + w * 1024 + lane * 16;
     auto issue_w1 = [&](int kt, int stage, int plane) {     // one of a step's three W pieces
         if (X6D(1) && kt >= kt0 + NW - 1) return;
-        const int k0 = (kt < nk ? kt : nk - 1) * TK;
-        dma16(pw[plane] + k0, smem + LDS_W + stage * WSTAGE_BYTES + plane * WP_BYTES + w * 1024);
+        const int kc = kt < nk ? kt : nk - 1;
+        unsigned char* dst = smem + LDS_W + stage * WSTAGE_BYTES + plane * WP_BYTES + w * 1024;
+        if (packed) dma16(wpk + ((size_t)kc * 3 + plane) * WP_BYTES, dst);
+        else dma16(pw[plane] + kc * TK, dst);
     };
     auto issue_w = [&](int kt, int stage) { issue_w1(kt, stage, 0); issue_w1(kt, stage, 1); issue_w1(kt, stage, 2); };
     u32x4_t araw[NA][2];
@@ -770,6 +777,28 @@ static int x6_var() {       // PGASR_X6_VAR (read at every call: A/B inside one 
     const char* e = getenv("PGASR_X6_VAR");
     return (e && e[0] == '0') ? 0 : 7;
 }
+// fp32 W (N x K; or stored K x N with transpose) -> the packed three-plane operand of x6c: [N/256][K/16][plane 3][row 256][2 chunks of 8 bf16],
+// the chunk at position cp of row r holding k-chunk cp ^ ((r >> 3) & 1) -- the LDS image itself.  One thread per 16-byte chunk position.
+__global__ __launch_bounds__(256) void pack_x6w_kernel(const float* __restrict__ src, int N, int K, int ld, int transpose, u32x4_t* __restrict__ dst) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over N * K / 8 chunk positions
+    if (idx >= (size_t)N * K / 8) return;
+    const int nk = K / 16;
+    const int pos = (int)(idx % 512), kt = (int)((idx / 512) % nk), tn = (int)(idx / 512 / nk);
+    const int r = pos >> 1, cp = pos & 1, c = cp ^ ((r >> 3) & 1);
+    const int n = tn * 256 + r, k0 = kt * 16 + c * 8;
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = transpose ? src[(size_t)(k0 + 2 * e) * ld + n] : src[(size_t)n * ld + k0 + 2 * e];
+        const float x1 = transpose ? src[(size_t)(k0 + 2 * e + 1) * ld + n] : src[(size_t)n * ld + k0 + 2 * e + 1];
+        split3(x0, x1, h[e], m[e], l[e]);
+    }
+    u32x4_t* blk = dst + ((size_t)tn * nk + kt) * 3 * 512 + pos;
+    blk[0] = (u32x4_t){h[0], h[1], h[2], h[3]};
+    blk[512] = (u32x4_t){m[0], m[1], m[2], m[3]};
+    blk[1024] = (u32x4_t){l[0], l[1], l[2], l[3]};
+}
+
 constexpr int X6_FEED_SPLIT_MAX = 32;      // split tiles per feed: 4 x 32 slabs of 256 KB = 32 MB of workspace
 // K in quarters for the first tiles of a feed (K >= 1024: the input-gradient feeds).  The K = 512 projections in quarters were measured
 // (round 4, PGASR_X6_QUARTER_K=512, same box, 2 x 40 steps each): forward sweeps 1.54 against 1.47 ms, step 10.67-10.70 against
@@ -789,6 +818,16 @@ extern "C" int pgasr_diag_x6_stamps(long long* out) {      // host copy of workg
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(x6_stamp_out), sizeof(long long) * 8 * 16) == hipSuccess ? 0 : 1;
 }
 #endif
+
+extern "C" int pgasr_pack_x6w_planes(const float* src, int rows, int cols, int ld, int transpose, void* pack, void* stream) {
+    if (!src || !pack || rows <= 0 || cols <= 0 || ld < cols) return PGASR_ERR_INVALID_ARG;
+    const int N = transpose ? cols : rows, K = transpose ? rows : cols;
+    if ((N % x6c::TN) || (K % x6c::TK) || (((size_t)pack) & 15)) return PGASR_ERR_UNSUPPORTED;
+    const size_t chunks = (size_t)N * K / 8;
+    PGASR_LAUNCH_KERNEL(pack_x6w_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, N, K, ld, transpose, (u32x4_t*)pack);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
 
 extern "C" int pgasr_split_bf16_planes3(const float* src, int rows, int cols, int ld, int transpose,
                                         unsigned short* hi, unsigned short* mid, unsigned short* lo, void* stream) {
@@ -810,7 +849,7 @@ static bool x6w_shape_ok(int M, int N, int K, const float* A, int lda, int ldc, 
 extern "C" int pgasr_gemm_x6w_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
                                   const unsigned short* Wmid, const unsigned short* Wlo, float* C, int ldc,
                                   const float* bias, const float* dact_y, float slope, void* stream) {
-    if (!A || !Whi || !Wmid || !Wlo || !C || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N) return PGASR_ERR_INVALID_ARG;
+    if (!A || !Whi || (!Wmid != !Wlo) || !C || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N) return PGASR_ERR_INVALID_ARG;     // Wmid == Wlo == NULL: Whi is a pack
     if (!x6w_shape_ok(M, N, K, A, lda, ldc, Whi, Wmid, Wlo)) return PGASR_ERR_UNSUPPORTED;
     const size_t lds = (size_t)x6c::LDS_BYTES;
     const int var = x6_var();
@@ -836,7 +875,7 @@ extern "C" int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int 
                                        const unsigned short* Wmid, const unsigned short* Wlo, float* C, int ldc, const float* bias,
                                        const unsigned* xcc_busy, unsigned* tiles_done, int order,
                                        void* workspace, size_t workspace_bytes, void* stream) {
-    if (!A || !Whi || !Wmid || !Wlo || !C || !tiles_done || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N) return PGASR_ERR_INVALID_ARG;
+    if (!A || !Whi || (!Wmid != !Wlo) || !C || !tiles_done || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N) return PGASR_ERR_INVALID_ARG;
     if (order < 0 || order > 1) return PGASR_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < 1024) return PGASR_ERR_WORKSPACE;
     if (!x6w_shape_ok(M, N, K, A, lda, ldc, Whi, Wmid, Wlo) || pgasr_gemm_x6w_feed_col_tiles(N) == 0) return PGASR_ERR_UNSUPPORTED;

@@ -644,7 +644,7 @@ def prepack_blstm_layers(layer_params, in_dims, rows=0):
             pk = prepack_blstm(params, in_dim)
             if counters is not None:
                 pk.fed_fwd, pk.fed_bwd, pk.slab = counters[2 * li], counters[2 * li + 1], counters[2 * nl + li]
-            for t in (pk.wih_perm, pk.bias_perm, pk.pack_f, pk.pack_b) + (pk.planes or ()) + (pk.planes_t or ()):
+            for t in (pk.wih_perm, pk.bias_perm, pk.pack_f, pk.pack_b) + tuple(pk.planes or ()) + tuple(pk.planes_t or ()):
                 streams.hold(t, main)
             out.append(pk)
         # ONE event for all layers (the packs take ~0.1 ms, the front end that runs meanwhile longer): a cross-stream wait

@@ -362,7 +362,24 @@ def gemm(A, B, C, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=N
     return C
 
 
-def split_planes(w, transpose=False, planes=None):
+X6_PACKED = _os_environ_get("PGASR_X6_PACKED", "1") != "0"     # three-plane weights as ONE buffer in the six-product kernel's LDS-image order
+
+
+class X6Pack:
+    """The three-plane weight operand of the six-product kernels, packed tile by tile (``pgasr_pack_x6w_planes``)."""
+    __slots__ = ("pack", "N", "K")
+
+    def __init__(self, pack, N, K):
+        self.pack, self.N, self.K = pack, N, K
+
+    def __len__(self):
+        return 3
+
+    def __iter__(self):          # tensors to keep alive / to hold across streams
+        return iter((self.pack,))
+
+
+def split_planes(w, transpose=False, planes=None, packed=None):
     """fp32 matrix (rows, cols) -> bf16 planes (int16 storage) of shape (rows, cols), or (cols, rows) with ``transpose``: the
     pre-split weight operand of ``gemm_x3w``.  planes = 2: (hi, lo), the bf16x3 kernels' operand; 3: (hi, mid, lo), the
     six-product kernels' (precision mode "f32"); None: what the current precision mode uses."""
@@ -375,6 +392,10 @@ def split_planes(w, transpose=False, planes=None):
         raise _lib.PgasrError("split_planes: 2 or 3 planes")
     rows, cols = w.shape
     shape = (cols, rows) if transpose else (rows, cols)
+    if planes == 3 and (X6_PACKED if packed is None else packed) and shape[0] % 256 == 0 and shape[1] % 16 == 0:
+        pack = torch.empty(shape[0] * shape[1] * 6, dtype=torch.uint8, device=w.device)
+        _lib.check(lib.pgasr_pack_x6w_planes(w.data_ptr(), rows, cols, w.stride(0), int(transpose), pack.data_ptr(), _stream()), "pgasr_pack_x6w_planes")
+        return X6Pack(pack, shape[0], shape[1])
     out = tuple(torch.empty(shape, dtype=torch.int16, device=w.device) for _ in range(planes))
     if planes == 3:
         st = lib.pgasr_split_bf16_planes3(w.data_ptr(), rows, cols, w.stride(0), int(transpose), *[t.data_ptr() for t in out], _stream())
@@ -392,7 +413,18 @@ def gemm_x3w_ok(M, N, K, lda=None, planes=2):
     return K % 32 == 0 and N % 128 == 0 and lda % 4 == 0 and M > 0
 
 
+def _plane_ptrs(planes):
+    """(hi, mid, lo) device addresses for the six-product entry points: a pack travels as hi with mid = lo = NULL."""
+    if isinstance(planes, X6Pack):
+        return planes.pack.data_ptr(), None, None
+    return tuple(t.data_ptr() for t in planes)
+
+
 def _check_planes(planes, N, K, what):
+    if isinstance(planes, X6Pack):
+        if (planes.N, planes.K) != (N, K) or not planes.pack.is_cuda:
+            raise _lib.PgasrError(f"{what}: packed planes are for a ({planes.N}, {planes.K}) weight, the product wants ({N}, {K})")
+        return
     if len(planes) not in (2, 3):
         raise _lib.PgasrError(f"{what}: planes must be a (hi, lo) or (hi, mid, lo) tuple")
     for t in planes:
@@ -410,7 +442,7 @@ def gemm_x3w(A, planes, C, M, N, K, lda=None, ldc=None, bias=None, dact_y=None, 
     _check_planes(planes, N, K, "gemm_x3w")
     with _timed("gemm_x6c" if len(planes) == 3 else "gemm_x3c"):
         if len(planes) == 3:
-            st = lib.pgasr_gemm_x6w_f32(M, N, K, A.data_ptr(), K if lda is None else lda, *[t.data_ptr() for t in planes],
+            st = lib.pgasr_gemm_x6w_f32(M, N, K, A.data_ptr(), K if lda is None else lda, *_plane_ptrs(planes),
                                         C.data_ptr(), N if ldc is None else ldc, _p(bias), _p(dact_y), float(slope), _stream())
         else:
             st = lib.pgasr_gemm_x3w_f32(M, N, K, A.data_ptr(), K if lda is None else lda, planes[0].data_ptr(), planes[1].data_ptr(),
@@ -565,7 +597,7 @@ def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done, order=0, ph
         if ws is None:
             ws = _workspace(lib.pgasr_gemm_x6w_feed_workspace_bytes(), C.device, "x6w_feed")
         with _timed("gemm_feed_x6c"):        # on the feeding stream: the time includes what the persistent workgroups wait for the sweep
-            st = lib.pgasr_gemm_x6w_feed_f32(M, N, K, A.data_ptr(), K, *[t.data_ptr() for t in planes], C.data_ptr(), N, _p(bias),
+            st = lib.pgasr_gemm_x6w_feed_f32(M, N, K, A.data_ptr(), K, *_plane_ptrs(planes), C.data_ptr(), N, _p(bias),
                                              busy_ptr, tiles_done.data_ptr(), int(order), _p(ws), ws.numel(), _stream())
         _lib.check(st, "pgasr_gemm_x6w_feed_f32")
         return C

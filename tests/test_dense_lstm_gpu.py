@@ -104,7 +104,7 @@ def test_gemm_x6w_six_product(M, N, K, with_bias, with_dact):
         want = want + bias.double()
     if with_dact:
         want = want * torch.where(y > 0, 1.0, 0.01).double()
-    planes = hipops.split_planes(W.to(DEV), planes=3)
+    planes = hipops.split_planes(W.to(DEV), planes=3, packed=False)
     assert len(planes) == 3
     parts = [(p_.cpu().to(torch.int32) << 16).view(torch.float32).double() for p_ in planes]
     assert float(((parts[0] + parts[1] + parts[2]) - W.double()).abs().max() / W.abs().max()) < 2.0 ** -23     # x = hi + mid + lo
@@ -114,6 +114,22 @@ def test_gemm_x6w_six_product(M, N, K, with_bias, with_dact):
     hipops.gemm_x3w(A.to(DEV), planes, C, M, N, K, bias=None if bias is None else bias.to(DEV),
                     dact_y=None if y is None else y.to(DEV), slope=0.01)
     e6 = rel_err(C.cpu(), want)
+    # the PACKED operand (the three planes tile by tile in the kernel's LDS-image order): the same bytes by another route, so the same bits
+    pack = hipops.split_planes(W.to(DEV), planes=3, packed=True)
+    assert isinstance(pack, hipops.X6Pack) and len(pack) == 3 and pack.pack.numel() == N * K * 6
+    img = pack.pack.view(torch.int16).view(N // 256, K // 16, 3, 256, 2, 8).cpu()          # [tile][step][plane][row][chunk position][8]
+    r = torch.arange(256)
+    for pl in range(3):
+        dense = planes[pl].cpu().view(N // 256, 256, K // 16, 2, 8).permute(0, 2, 1, 3, 4)    # [tile][step][row][k-chunk][8]
+        for cp in range(2):
+            assert torch.equal(img[:, :, pl, :, cp, :], dense[:, :, r, cp ^ ((r >> 3) & 1), :])
+    Cp = torch.full((M, N), float("nan"), device=DEV)
+    hipops.gemm_x3w(A.to(DEV), pack, Cp, M, N, K, bias=None if bias is None else bias.to(DEV), dact_y=None if y is None else y.to(DEV), slope=0.01)
+    assert torch.equal(Cp, C)
+    pack_t = hipops.split_planes(W.t().contiguous().to(DEV), transpose=True, planes=3, packed=True)
+    assert torch.equal(pack_t.pack, pack.pack)
+    with pytest.raises(Exception):
+        hipops.gemm_x3w(A.to(DEV)[:, :K - 16].contiguous(), pack, Cp, M, N, K - 16)        # a pack knows the product it was made for
     # the fp32 MFMA kernel on the same product: the six-product result must be of the same quality
     C0 = torch.empty(M, N, device=DEV)
     hipops.gemm(A.to(DEV), W.to(DEV), C0, M, N, K, transB=True, bias=None if bias is None else bias.to(DEV), precision=0)
@@ -122,7 +138,7 @@ def test_gemm_x6w_six_product(M, N, K, with_bias, with_dact):
     e0 = rel_err(C0.cpu(), want)
     print(f"[x6w] M={M} N={N} K={K}: six-product {e6:.2e}  fp32 MFMA {e0:.2e}")
     assert e6 < 2e-6 and e6 < 4 * e0 + 2e-7
-    planes_t = hipops.split_planes(W.t().contiguous().to(DEV), transpose=True, planes=3)
+    planes_t = hipops.split_planes(W.t().contiguous().to(DEV), transpose=True, planes=3, packed=False)
     assert all(torch.equal(a, b) for a, b in zip(planes_t, planes))
     assert hipops.gemm_x3w_ok(M, N, K, planes=3) and not hipops.gemm_x3w_ok(M, N + 128, K, planes=3) and not hipops.gemm_x3w_ok(M, N, K + 8, planes=3)
 

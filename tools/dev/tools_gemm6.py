@@ -25,21 +25,22 @@ for N, K in ((2048, 512), (512, 2048)):
     A = torch.randn(M, K, generator=g).to(dev)
     W = (torch.randn(N, K, generator=g) * 0.05).to(dev)
     C = torch.empty(M, N, device=dev)
-    p2 = hipops.split_planes(W, planes=2); p3 = hipops.split_planes(W, planes=3)
+    p2 = hipops.split_planes(W, planes=2); p3 = hipops.split_planes(W, planes=3, packed=False); p3p = hipops.split_planes(W, planes=3, packed=True)
     ref = (A[:512].double() @ W.double().t()).cpu()
     res = {}
     e2 = e0 = float("nan")
     if not QUICK:
         res["x3c (bf16x3)"] = timeit(lambda: hipops.gemm_x3w(A, p2, C, M, N, K)); e2 = float((C[:512].double().cpu() - ref).abs().max() / ref.abs().max())
     res["x6c (six products)"] = timeit(lambda: hipops.gemm_x3w(A, p3, C, M, N, K)); e3 = float((C[:512].double().cpu() - ref).abs().max() / ref.abs().max())
+    res["x6c packed W"] = timeit(lambda: hipops.gemm_x3w(A, p3p, C, M, N, K)); e3p = float((C[:512].double().cpu() - ref).abs().max() / ref.abs().max()); assert e3p == e3
     if not QUICK:
         res["fp32 MFMA"] = timeit(lambda: hipops.gemm(A, W, C, M, N, K, transB=True, precision=0), reps=5); e0 = float((C[:512].double().cpu() - ref).abs().max() / ref.abs().max())
     gf = 2.0 * M * N * K / 1e9
     for k, us in res.items():
-        print(f"C=A W^T M={M} N={N} K={K}: {k:22s} {us:7.1f} us  {gf / us:7.1f} TF fp32-equivalent", flush=True)
+        print(f"C=A W^T M={M} N={N} K={K}: {k:22s} {us:7.1f} us  {gf / us * 1e3:7.1f} TF fp32-equivalent", flush=True)
     print(f"   max-norm error vs fp64: bf16x3 {e2:.2e}  six-product {e3:.2e}  fp32 MFMA {e0:.2e}", flush=True)
     us6 = res["x6c (six products)"]
-    print(f"   six-product issued bf16: {6 * gf / us6 / 1e3:.3f} PF = {6 * gf / us6 / 1e3 / 2.5:.1%} of 2.5 PF", flush=True)
+    print(f"   six-product issued bf16: {6 * gf / us6:.3f} PF = {6 * gf / us6 / 2.5:.1%} of 2.5 PF", flush=True)
 
 Mw, Nw, Kw = 2048, 512, 32000
 A = torch.randn(Kw, Mw, generator=g).to(dev); B = torch.randn(Kw, Nw, generator=g).to(dev)
