@@ -39,7 +39,7 @@ typedef enum pgasr_status {
 
 /* 4 (round 3): pgasr_adam_step(guards, applied), pgasr_lstm_pack_weights(planes), the feed phases, and the streamed order:
  * pgasr_lstm_wgrad_slabs, pgasr_lstm_layer_bwd_streamed, pgasr_lstm_wgrads_streamed(+_workspace_bytes), pgasr_stream_gate_sum. */
-#define PGASR_ABI_VERSION 5
+#define PGASR_ABI_VERSION 6
 
 int pgasr_abi_version(void);
 const char* pgasr_status_string(int status);
@@ -69,24 +69,38 @@ int pgasr_ctc_loss_grad(const float* log_probs, const int32_t* targets,
 
 /* The gradient pass of pgasr_ctc_loss_grad on its own, over the lattice that an earlier
  * pgasr_ctc_loss_grad(..., grad_logits = NULL, ...) call with the same T, B, V, Lmax left in `workspace`
- * (so the lattice can run on another stream beside the kernels that produce pg_coef). */
+ * (so the lattice can run on another stream beside the kernels that produce pg_coef).
+ * pg_coef_per_frame != 0: pg_coef is (T,B), one coefficient per frame (pgasr_pg_step_coefs), instead of (B,). */
 int pgasr_ctc_grad_from_lattice(const float* log_probs, const int32_t* input_lengths,
                                 const int32_t* target_lengths, int T, int B, int V, int Lmax, int blank,
                                 const float* utt_scale, const float* pg_coef, const int32_t* pg_path,
-                                float* grad_logits, void* workspace, size_t workspace_bytes, void* stream);
+                                int pg_coef_per_frame, float* grad_logits, void* workspace, size_t workspace_bytes,
+                                void* stream);
 
 /* Rewards and gradient coefficients (policy_grad.py:4-16 intent):
  *   dist [2B]: edit distances of the greedy paths, then of the sampled paths (pgasr_edit_distance);
  *   R = -dist / max(L,1);  pg_coef = lam * inv_global_batch * (R_sample - R_greedy);
  *   utt_scale = inv_global_batch / max(L,1).
  * pgasr_pg_loss_value: terms[b] = nll[b]*utt_scale[b] - pg_coef[b] * sum_{t<input_lengths[b]} log_probs[t,b,path[t,b]]
- *   (pg_coef and path both NULL: CTC only); the objective's value is sum_b terms[b].  Deterministic. */
+ *   (pg_coef and path both NULL: CTC only); the objective's value is sum_b terms[b].  Deterministic.
+ *   pg_coef_per_frame != 0: pg_coef is (T,B) and the second term is sum_t pg_coef[t,b] * log_probs[t,b,path[t,b]].
+ * pgasr_pg_step_coefs: per-frame coefficients from the PER-STEP rewards of policy_grad.py:10-15 (the reference computes r_t and
+ *   never consumes it; this is the build's use of it, opt-in).  With yhat the collapsed path, d(i) = ED(y, yhat[:i]) and
+ *   rho_j = d(j-1) - d(j) the reward of character j (reference: r_1 = rho_1 + rho_2, r_t = rho_{t+1} for t >= 2), the reward-to-go
+ *   of frame t is G(t) = d(c(t)) - d(|yhat|), c(t) = characters that start in frames < t, and
+ *     coef[t,b] = lam * inv_global_batch * (G_sample(t) - G_greedy(t)) / max(L_b,1)   for t < input_lengths[b], else 0
+ *   (baseline = the greedy path's reward-to-go at the same frame; coef[0,b] is pgasr_pg_rewards' pg_coef[b]).
+ *   paths (2,T,B) = greedy then sampled frame labels; prefix_dist (2B, prefix_stride) and token_lengths (2B) = the per-prefix
+ *   distances and lengths of their collapsed forms (pgasr_edit_distance with prefix_dist, pgasr_ctc_collapse). */
 int pgasr_pg_rewards(const int32_t* dist, const int32_t* target_lengths, int B, float lam,
                      float inv_global_batch, float* R_greedy, float* R_sample, float* pg_coef,
                      float* utt_scale, void* stream);
 int pgasr_pg_loss_value(const float* log_probs, const int32_t* path, const int32_t* input_lengths,
                         const float* nll, const float* utt_scale, const float* pg_coef,
-                        int T, int B, int V, float* terms, void* stream);
+                        int T, int B, int V, int pg_coef_per_frame, float* terms, void* stream);
+int pgasr_pg_step_coefs(const int32_t* paths, const int32_t* input_lengths, const int32_t* prefix_dist, int prefix_stride,
+                        const int32_t* token_lengths, const int32_t* target_lengths, int T, int B, int blank,
+                        float lam, float inv_global_batch, float* coef, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A9 / A12  per-frame best label and sampled label.

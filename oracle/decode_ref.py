@@ -226,6 +226,47 @@ def sample_paths(logits, seed, offset=0):
     return paths.astype(np.int64), cdf, u
 
 
+def step_rewards(true_y, pred):
+    """The reference's per-step rewards as it evidently means them (policy_grad.py:10-15 with element [0] of edit_dist's tuple):
+    r_1 = |y| - ED(y, pred[:2]),  r_t = ED(y, pred[:t]) - ED(y, pred[:t+1]) for t > 1; returned for t = 1 .. len(pred)."""
+    out = []
+    for t in range(1, len(pred) + 1):
+        if t > 1:
+            out.append(-(edit_dist(true_y, pred[:t + 1])[0] - edit_dist(true_y, pred[:t])[0]))
+        else:
+            out.append(-(edit_dist(true_y, pred[:t + 1])[0] - len(true_y)))
+    return out
+
+
+def reward_to_go(path, true_y, blank=0):
+    """Per-frame reward-to-go of one frame path (1-D ints, its valid frames only): character j of the collapsed path earns
+    rho_j = ED(y, yhat[:j-1]) - ED(y, yhat[:j]) at the frame where it starts; G[t] = sum of rho_j over the characters that start at
+    frames >= t.  (In the reference's r_t: r_1 = rho_1 + rho_2, r_t = rho_{t+1}.)  Summed character by character, no telescoping."""
+    starts, seq, prev = [], [], -1
+    for t, k in enumerate(path):
+        k = int(k)
+        if k != prev and k != blank:
+            starts.append(t); seq.append(k)
+        prev = k
+    # d[i] = ED(y, seq[:i]) row by row (the recurrence of edit_dist above, keeping every row's last entry)
+    n = len(true_y)
+    row = list(range(n + 1))
+    d = [n]
+    for i in range(1, len(seq) + 1):
+        diag, row[0] = row[0], i
+        for jj in range(1, n + 1):
+            up = row[jj]
+            row[jj] = diag if seq[i - 1] == true_y[jj - 1] else 1 + min(row[jj - 1], diag, up)
+            diag = up
+        d.append(row[n])
+    rho = [d[j - 1] - d[j] for j in range(1, len(seq) + 1)]
+    per_frame = np.zeros(len(path), dtype=np.float64)
+    for r, st in zip(rho, starts):
+        per_frame[st] += r
+    G = per_frame[::-1].cumsum()[::-1].copy()                 # G[t] = sum of the rewards earned at frames >= t
+    return G, seq, rho
+
+
 def reinforce_grad(logits, paths, coef, lengths):
     """d/dlogits of  sum_b coef[b] * ( - sum_{t<len_b} log softmax(logits)[t,b,path] )
     = coef[b] * (softmax - onehot(path)), zero for t >= len_b  (SURVEY §8a A12,
@@ -238,6 +279,7 @@ def reinforce_grad(logits, paths, coef, lengths):
     onehot = np.zeros_like(sm)
     tt, bb = np.meshgrid(np.arange(T), np.arange(B), indexing="ij")
     onehot[tt, bb, np.asarray(paths)] = 1.0
-    g = (sm - onehot) * np.asarray(coef, dtype=np.float64)[None, :, None]
+    coef = np.asarray(coef, dtype=np.float64)
+    g = (sm - onehot) * (coef[None, :, None] if coef.ndim == 1 else coef[:, :, None])      # (B,) per utterance or (T,B) per frame
     mask = (np.arange(T)[:, None] < np.asarray(lengths)[None, :])
     return g * mask[..., None]

@@ -27,10 +27,12 @@ SIGNATURES = {
     "pgasr_ctc_loss_grad": (C.c_int, [c_f32p, c_i32p, c_i32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_ptr, C.c_size_t, c_ptr]),
     "pgasr_ctc_grad_from_lattice": (C.c_int, [c_f32p, c_i32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                              c_f32p, c_f32p, c_i32p, c_f32p, c_ptr, C.c_size_t, c_ptr]),
+                                              c_f32p, c_f32p, c_i32p, C.c_int, c_f32p, c_ptr, C.c_size_t, c_ptr]),
     "pgasr_pg_rewards": (C.c_int, [c_i32p, c_i32p, C.c_int, C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_ptr]),
-    "pgasr_pg_loss_value": (C.c_int, [c_f32p, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
+    "pgasr_pg_loss_value": (C.c_int, [c_f32p, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       c_f32p, c_ptr]),
+    "pgasr_pg_step_coefs": (C.c_int, [c_i32p, c_i32p, c_i32p, C.c_int, c_i32p, c_i32p, C.c_int, C.c_int, C.c_int,
+                                      C.c_float, C.c_float, c_f32p, c_ptr]),
     "pgasr_frame_argmax_sample": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
                                             c_i32p, c_i32p, c_ptr]),
     "pgasr_batch_prep": (C.c_int, [c_f32p, C.c_int, C.c_int, c_ptr, c_ptr, C.c_int, c_i32p, c_i32p, c_i32p, c_ptr]),
@@ -133,7 +135,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.pgasr_abi_version() != 5:
+    if lib.pgasr_abi_version() != 6:
         raise PgasrError("libpgasr_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const float* __restrict__ lp, const int32_t* __restrict__ in_len, const int32_t* __restrict__ tg_len,
     int T, int B, int V, int Lmax, int Smax, int blank, CtcWs ws,
     const float* __restrict__ utt_scale, const float* __restrict__ pg_coef,
-    const int32_t* __restrict__ pg_path, float* __restrict__ grad) {
+    const int32_t* __restrict__ pg_path, int coef_per_frame, float* __restrict__ grad) {
     const int lane = threadIdx.x & 63;
     const long long w = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (w >= (long long)T * B) return;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     }
     if (pg_coef != nullptr && pg_path != nullptr) {
         const int k = pg_path[(size_t)t * B + b];
-        g += pg_coef[b] * (sm - (lane == k ? 1.f : 0.f));
+        g += pg_coef[coef_per_frame ? (size_t)t * B + b : (size_t)b] * (sm - (lane == k ? 1.f : 0.f));
     }
     if (lane < V) grad[o + lane] = g;
 }
@@ -395,7 +395,7 @@ extern "C" int pgasr_ctc_loss_grad(const float* log_probs, const int32_t* target
         const unsigned blocks = (unsigned)((waves + wpb - 1) / wpb);
         PGASR_LAUNCH_KERNEL(ctc_grad_kernel, dim3(blocks), dim3(64 * wpb), 0, st,
                            log_probs, input_lengths, target_lengths, T, B, V,
-                           Lmax > 0 ? Lmax : 1, Smax, blank, ws, utt_scale, pg_coef, pg_path, grad_logits);
+                           Lmax > 0 ? Lmax : 1, Smax, blank, ws, utt_scale, pg_coef, pg_path, 0, grad_logits);
         PGASR_CHECK_LAUNCH();
     }
     return PGASR_OK;
@@ -408,7 +408,8 @@ extern "C" int pgasr_ctc_loss_grad(const float* log_probs, const int32_t* target
 extern "C" int pgasr_ctc_grad_from_lattice(const float* log_probs, const int32_t* input_lengths,
                                            const int32_t* target_lengths, int T, int B, int V, int Lmax, int blank,
                                            const float* utt_scale, const float* pg_coef, const int32_t* pg_path,
-                                           float* grad_logits, void* workspace, size_t workspace_bytes, void* stream) {
+                                           int pg_coef_per_frame, float* grad_logits, void* workspace, size_t workspace_bytes,
+                                           void* stream) {
     if (!log_probs || !input_lengths || !target_lengths || !grad_logits) return PGASR_ERR_INVALID_ARG;
     if (T <= 0 || B <= 0 || V <= 0 || Lmax < 0 || blank < 0 || blank >= V) return PGASR_ERR_INVALID_ARG;
     if ((pg_coef == nullptr) != (pg_path == nullptr)) return PGASR_ERR_INVALID_ARG;
@@ -422,7 +423,7 @@ extern "C" int pgasr_ctc_grad_from_lattice(const float* log_probs, const int32_t
     const unsigned blocks = (unsigned)((waves + wpb - 1) / wpb);
     PGASR_LAUNCH_KERNEL(ctc_grad_kernel, dim3(blocks), dim3(64 * wpb), 0, (hipStream_t)stream,
                        log_probs, input_lengths, target_lengths, T, B, V,
-                       Lmax > 0 ? Lmax : 1, Smax, blank, ws, utt_scale, pg_coef, pg_path, grad_logits);
+                       Lmax > 0 ? Lmax : 1, Smax, blank, ws, utt_scale, pg_coef, pg_path, pg_coef_per_frame ? 1 : 0, grad_logits);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }

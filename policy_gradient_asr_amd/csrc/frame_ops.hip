@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void pg_rewards_kernel(const int32_t* __restri
 __global__ __launch_bounds__(256) void pg_loss_value_kernel(const float* __restrict__ lp, const int32_t* __restrict__ path,
                                                             const int32_t* __restrict__ in_len, const float* __restrict__ nll,
                                                             const float* __restrict__ utt_scale, const float* __restrict__ coef,
-                                                            int T, int B, int V, float* __restrict__ terms) {
+                                                            int T, int B, int V, int coef_per_frame,
+                                                            float* __restrict__ terms) {
     __shared__ float red[256];
     const int b = blockIdx.x;
     const int Tb = min(in_len[b], T);
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(256) void pg_loss_value_kernel(const float* __restr
     if (path && coef)
         for (int t = threadIdx.x; t < Tb; t += 256) {
             const int k = path[(size_t)t * B + b];
-            s += lp[((size_t)t * B + b) * V + k];
+            const float v = lp[((size_t)t * B + b) * V + k];
+            s += coef_per_frame ? coef[(size_t)t * B + b] * v : v;
         }
     red[threadIdx.x] = s;
     __syncthreads();
@@ -157,7 +159,45 @@ __global__ __launch_bounds__(256) void pg_loss_value_kernel(const float* __restr
         if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) terms[b] = nll[b] * utt_scale[b] - (coef ? coef[b] * red[0] : 0.f);
+    if (threadIdx.x == 0) terms[b] = nll[b] * utt_scale[b] - (coef ? (coef_per_frame ? red[0] : coef[b] * red[0]) : 0.f);
+}
+
+// Per-frame REINFORCE coefficients from the per-step rewards of policy_grad.py:10-15 (reward_mode "per_step").
+// rho_j = ED(y, yhat[:j-1]) - ED(y, yhat[:j]) is what character j of the collapsed path earns (the reference's r_t in these terms:
+// r_1 = rho_1 + rho_2, r_t = rho_{t+1} for t >= 2; they telescope to |y| - ED(y, yhat)).  The reward-to-go of frame t is the sum over
+// the characters that START at frames >= t:  G(t) = ED(y, yhat[:c(t)]) - ED(y, yhat),  c(t) = characters started in frames < t.
+//   coef[t,b] = lam/Bg * (G_sample(t) - G_greedy(t)) / max(|y|,1)      (0 for t >= T_b)
+// the greedy path's reward-to-go at the same frame is the baseline (it does not depend on the sampled action); frame 0 carries the
+// utterance-level coefficient lam/Bg (R_s - R_g) of pg_rewards_kernel.  One wave per utterance, the character count by ballots.
+__global__ __launch_bounds__(64) void pg_step_coef_kernel(const int32_t* __restrict__ paths, const int32_t* __restrict__ in_len,
+                                                          const int32_t* __restrict__ prefix, int pstride,
+                                                          const int32_t* __restrict__ tok_len, const int32_t* __restrict__ tg_len,
+                                                          int T, int B, int blank, float lam, float inv_bg, float* __restrict__ coef) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int Tb = in_len[b]; Tb = Tb < 0 ? 0 : (Tb > T ? T : Tb);
+    const int L = tg_len[b];
+    const float k = lam * inv_bg / (float)(L > 1 ? L : 1);
+    const int32_t* pd[2] = {prefix + (size_t)b * pstride, prefix + (size_t)(B + b) * pstride};
+    int n[2] = {tok_len[b], tok_len[B + b]};
+    int carry[2] = {0, 0};
+    for (int w = 0; w < 2; ++w) n[w] = n[w] < 0 ? 0 : (n[w] > pstride - 1 ? pstride - 1 : n[w]);
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        float G[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int32_t* p = paths + (size_t)w * T * B;
+            const int cur = t < Tb ? p[(size_t)t * B + b] : blank;
+            const int prev = (t > 0 && t < Tb) ? p[(size_t)(t - 1) * B + b] : blank;
+            const bool start = t < Tb && cur != blank && (t == 0 || cur != prev);
+            const unsigned long long m = __ballot(start);
+            int c = carry[w] + __popcll(m & ((1ull << lane) - 1ull));
+            carry[w] += __popcll(m);
+            c = c > n[w] ? n[w] : c;
+            G[w] = (float)(pd[w][c] - pd[w][n[w]]);
+        }
+        if (t < T) coef[(size_t)t * B + b] = t < Tb ? k * (G[1] - G[0]) : 0.f;
+    }
 }
 
 }  // namespace
@@ -257,11 +297,23 @@ extern "C" int pgasr_pg_rewards(const int32_t* dist, const int32_t* target_lengt
 
 extern "C" int pgasr_pg_loss_value(const float* log_probs, const int32_t* path, const int32_t* input_lengths,
                                    const float* nll, const float* utt_scale, const float* pg_coef,
-                                   int T, int B, int V, float* terms, void* stream) {
+                                   int T, int B, int V, int pg_coef_per_frame, float* terms, void* stream) {
     if (!log_probs || !input_lengths || !nll || !utt_scale || !terms || T <= 0 || B <= 0 || V <= 0) return PGASR_ERR_INVALID_ARG;
     if ((pg_coef == nullptr) != (path == nullptr)) return PGASR_ERR_INVALID_ARG;
     PGASR_LAUNCH_KERNEL(pg_loss_value_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream,
-                       log_probs, path, input_lengths, nll, utt_scale, pg_coef, T, B, V, terms);
+                       log_probs, path, input_lengths, nll, utt_scale, pg_coef, T, B, V, pg_coef_per_frame ? 1 : 0, terms);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
+
+extern "C" int pgasr_pg_step_coefs(const int32_t* paths, const int32_t* input_lengths, const int32_t* prefix_dist, int prefix_stride,
+                                   const int32_t* token_lengths, const int32_t* target_lengths, int T, int B, int blank,
+                                   float lam, float inv_global_batch, float* coef, void* stream) {
+    if (!paths || !input_lengths || !prefix_dist || !token_lengths || !target_lengths || !coef) return PGASR_ERR_INVALID_ARG;
+    if (T <= 0 || B <= 0 || prefix_stride < 1 || blank < 0) return PGASR_ERR_INVALID_ARG;
+    PGASR_LAUNCH_KERNEL(pg_step_coef_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream,
+                       paths, input_lengths, prefix_dist, prefix_stride, token_lengths, target_lengths, T, B, blank, lam,
+                       inv_global_batch, coef);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }

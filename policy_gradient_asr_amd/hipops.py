@@ -167,6 +167,15 @@ def ctc_lattice(log_probs, targets, input_lengths, target_lengths, blank=0):
     return nll, (ws, Lmax, blank)
 
 
+def _coef_per_frame(pg_coef, T, B):
+    """pg_coef (B,): one coefficient per utterance; (T,B): one per frame (pg_step_coefs)."""
+    if pg_coef is None or pg_coef.numel() == B and pg_coef.dim() == 1:
+        return 0
+    if tuple(pg_coef.shape) != (T, B):
+        raise _lib.PgasrError(f"pg_coef must be (B,) or (T,B) = ({B},) / ({T},{B}); got {tuple(pg_coef.shape)}")
+    return 1
+
+
 def ctc_grad_from_lattice(log_probs, input_lengths, target_lengths, handle, utt_scale=None, pg_coef=None, pg_path=None):
     lib = _lib.load()
     ws, Lmax, blank = handle
@@ -174,7 +183,8 @@ def ctc_grad_from_lattice(log_probs, input_lengths, target_lengths, handle, utt_
     _req(utt_scale, torch.float32, "utt_scale"); _req(pg_coef, torch.float32, "pg_coef"); _req(pg_path, torch.int32, "pg_path")
     grad = torch.empty_like(log_probs)
     st = lib.pgasr_ctc_grad_from_lattice(_p(log_probs), _p(input_lengths), _p(target_lengths), T, B, V, Lmax, blank,
-                                         _p(utt_scale), _p(pg_coef), _p(pg_path), _p(grad), _p(ws), ws.numel(), _stream())
+                                         _p(utt_scale), _p(pg_coef), _p(pg_path), _coef_per_frame(pg_coef, T, B), _p(grad), _p(ws),
+                                         ws.numel(), _stream())
     _lib.check(st, "pgasr_ctc_grad_from_lattice")
     return grad
 
@@ -201,9 +211,25 @@ def pg_loss_value(log_probs, path, input_lengths, nll, utt_scale, pg_coef):
     _req(utt_scale, torch.float32, "utt_scale"); _req(pg_coef, torch.float32, "pg_coef")
     terms = torch.empty(B, dtype=torch.float32, device=log_probs.device)
     st = lib.pgasr_pg_loss_value(_p(log_probs), _p(path), _p(input_lengths), _p(nll), _p(utt_scale), _p(pg_coef),
-                                 T, B, V, _p(terms), _stream())
+                                 T, B, V, _coef_per_frame(pg_coef, T, B), _p(terms), _stream())
     _lib.check(st, "pgasr_pg_loss_value")
     return terms
+
+
+def pg_step_coefs(paths, input_lengths, prefix_dist, token_lengths, target_lengths, lam, inv_global_batch, blank=0):
+    """Per-frame REINFORCE coefficients (T,B) from the per-step rewards (policy_grad.py:10-15; include/pgasr_hip.h):
+    paths (2,T,B) greedy then sampled frame labels, prefix_dist (2B, P) / token_lengths (2B) of their collapsed forms."""
+    lib = _lib.load()
+    _req(paths, torch.int32, "paths"); _req(prefix_dist, torch.int32, "prefix_dist"); _req(token_lengths, torch.int32, "token_lengths")
+    _req(input_lengths, torch.int32, "input_lengths"); _req(target_lengths, torch.int32, "target_lengths")
+    two, T, B = paths.shape
+    if two != 2 or prefix_dist.shape[0] != 2 * B or token_lengths.numel() != 2 * B or target_lengths.numel() != B:
+        raise _lib.PgasrError("pg_step_coefs wants paths (2,T,B), prefix_dist (2B,P), token_lengths (2B,), target_lengths (B,)")
+    coef = torch.empty(T, B, dtype=torch.float32, device=paths.device)
+    st = lib.pgasr_pg_step_coefs(_p(paths), _p(input_lengths), _p(prefix_dist), prefix_dist.shape[1], _p(token_lengths),
+                                 _p(target_lengths), T, B, int(blank), float(lam), float(inv_global_batch), _p(coef), _stream())
+    _lib.check(st, "pgasr_pg_step_coefs")
+    return coef
 
 
 def frame_argmax_sample(scores, seed=0, offset=0, want_greedy=True, want_sample=True, batch_stride=0, batch_offset=0):

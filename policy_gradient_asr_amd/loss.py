@@ -39,6 +39,11 @@ class PGCTCLossFn(torch.autograd.Function):
     reference's per-step r_t (policy_grad.py:10-15) telescope to |y| - ED(y, yhat), i.e. to the
     same R up to the constant |y| that the baseline subtracts; the per-t values themselves are available from
     policy_grad.rewards_all_t, and the gradient uses their sum (one coefficient per utterance).
+    ``per_step = True`` (opt-in) puts the per-step rewards themselves into the gradient, as rewards-to-go: the coefficient of
+    frame t becomes lam/Bg (G_s(t) - G_g(t)) / max(L,1) with G(t) = ED(y, yhat[:c(t)]) - ED(y, yhat) the sum of the rewards of the
+    characters that start at frames >= t (c(t) = characters started before t), for the sampled path and -- the baseline -- for the
+    greedy path at the same frame (``pgasr_pg_step_coefs``); frame 0 carries the utterance coefficient.  Greedy baseline only (a
+    beam hypothesis has no frame alignment).
     Returns (loss, stats) where stats = (nll (B), R_s (B), R_g (B)) detached."""
 
     _lattice_streams = {}      # one side stream per calling stream
@@ -49,8 +54,10 @@ class PGCTCLossFn(torch.autograd.Function):
     unit_seed_ptr = None
     unit_hits = 0              # how often the shortcut was taken (tests)
     @staticmethod
-    def forward(ctx, logits, in_len, targets, tg_len, lam, seed, offset, global_batch, blank, beam=0, sample_base=-1):
+    def forward(ctx, logits, in_len, targets, tg_len, lam, seed, offset, global_batch, blank, beam=0, sample_base=-1, per_step=False):
         T, B, V = logits.shape
+        if per_step and beam > 0:
+            raise ValueError("per-step rewards need the frame-aligned greedy baseline (beam = 0)")
         dev = logits.device
         lp = hipops.log_softmax_rows(logits.contiguous())
         # The alpha/beta lattice (96 workgroups, a serial chain of T frames, ~0.27 ms at T=1000) is the long pole of this
@@ -75,8 +82,14 @@ class PGCTCLossFn(torch.autograd.Function):
                 greedy, sample = hipops.frame_argmax_sample(lp, seed=seed, offset=offset, **lay)
                 paths = torch.stack((greedy, sample), dim=0)                          # (2,T,B)
                 tokens, tok_len = hipops.ctc_collapse(paths, in_len, blank=blank)     # (2,B,T), (2,B)
-            dist = hipops.edit_distance(targets.repeat(2, 1), tg_len.repeat(2), tokens.view(2 * B, T), tok_len.view(2 * B))
+            if per_step:
+                dist, prefix = hipops.edit_distance(targets.repeat(2, 1), tg_len.repeat(2), tokens.view(2 * B, T), tok_len.view(2 * B),
+                                                    want_prefix=True)
+            else:
+                dist = hipops.edit_distance(targets.repeat(2, 1), tg_len.repeat(2), tokens.view(2 * B, T), tok_len.view(2 * B))
             R_g, R_s, coef, utt_scale = hipops.pg_rewards(dist, tg_len, lam, 1.0 / float(global_batch))
+            if per_step:
+                coef = hipops.pg_step_coefs(paths, in_len, prefix, tok_len.view(2 * B), tg_len, lam, 1.0 / float(global_batch), blank=blank)
         nll, lattice = hipops.ctc_lattice(lp, targets, in_len, tg_len, blank=blank)
         main.wait_stream(side)
         for t_ in (sample, R_g, R_s, coef, utt_scale):
@@ -93,17 +106,18 @@ class PGCTCLossFn(torch.autograd.Function):
         (grad,) = ctx.saved_tensors
         if PGCTCLossFn.unit_seed_ptr is not None and g.data_ptr() == PGCTCLossFn.unit_seed_ptr and g.numel() == 1:
             PGCTCLossFn.unit_hits += 1
-            return grad, None, None, None, None, None, None, None, None, None, None
-        return grad * g, None, None, None, None, None, None, None, None, None, None
+            return (grad,) + (None,) * 11
+        return (grad * g,) + (None,) * 11
 
 
-def pg_ctc_loss(logits, in_len, targets, tg_len, lam=1.0, seed=0, offset=0, global_batch=None, blank=0, beam=0, sample_base=-1):
+def pg_ctc_loss(logits, in_len, targets, tg_len, lam=1.0, seed=0, offset=0, global_batch=None, blank=0, beam=0, sample_base=-1,
+                per_step=False):
     """beam > 0: the baseline reward comes from the prefix-beam-search hypothesis of that width (see PGCTCLossFn).
     sample_base >= 0 (data parallel): index of this shard's first utterance in the global batch; the sampled paths are
     then those of the single-process global batch with the same seed."""
     B = logits.shape[1]
     return PGCTCLossFn.apply(logits, in_len, targets, tg_len, float(lam), int(seed), int(offset),
-                             int(global_batch or B), int(blank), int(beam), int(sample_base))
+                             int(global_batch or B), int(blank), int(beam), int(sample_base), bool(per_step))
 
 
 class CTCLoss(nn.Module):

@@ -230,14 +230,21 @@ class PolicyGradientTrainer(DataParallelStep):
     identity with the single-process run does not hold."""
 
     def __init__(self, model, lr=5e-4, lam=1.0, seed=0, blank=0, world_size=1, process_group=None, rank=0,
-                 reward_decoder="greedy", beam_size=16, precision=None):
-        """reward_decoder: which hypothesis the self-critical baseline reward comes from -- "greedy" (best path) or
+                 reward_decoder="greedy", beam_size=16, precision=None, reward_mode="utterance"):
+        """reward_mode: "utterance" (default) -- one reward R = -ED / |y| per utterance, the sum of the reference's per-step rewards
+        (policy_grad.py:10-15) up to a constant the baseline removes; "per_step" -- the per-step rewards themselves, as rewards-to-go
+        per frame against the greedy path's reward-to-go at the same frame (loss.PGCTCLossFn; greedy baseline only).
+        reward_decoder: which hypothesis the self-critical baseline reward comes from -- "greedy" (best path) or
         "beam": the reference's own reward definition (policy_grad.py:6-8: prefix beam search -> collapse_fn ->
         edit distance), decoded on the device with ``beam_size`` (BASELINE config 5: 16; the reference passes 5)."""
         super().__init__(model, lr=lr, world_size=world_size, process_group=process_group, precision=precision)
         if reward_decoder not in ("greedy", "beam"):
             raise ValueError("reward_decoder must be 'greedy' or 'beam'")
-        self.reward_decoder, self.beam_size = reward_decoder, int(beam_size)
+        if reward_mode not in ("utterance", "per_step"):
+            raise ValueError("reward_mode must be 'utterance' or 'per_step'")
+        if reward_mode == "per_step" and reward_decoder != "greedy":
+            raise ValueError("per-step rewards need the frame-aligned greedy baseline (reward_decoder='greedy')")
+        self.reward_decoder, self.beam_size, self.reward_mode = reward_decoder, int(beam_size), reward_mode
         self.lam = lam
         # ONE sampling seed for all ranks: a rank addresses its draws by GLOBAL utterance index (contiguous shards: rank *
         # local batch), so N ranks sample exactly the paths of one process holding the whole batch -- the N-rank REINFORCE
@@ -340,6 +347,7 @@ class PolicyGradientTrainer(DataParallelStep):
         loss, nll, R_s, R_g = pg_ctc_loss(logits, in_len, tg, tg_len, lam=self.lam, seed=self.seed,
                                           offset=self.nstep + 1, global_batch=global_batch, blank=self.blank,
                                           beam=self.beam_size if self.reward_decoder == "beam" else 0,
-                                          sample_base=self.rank * x.shape[0] if self.world > 1 else -1)
+                                          sample_base=self.rank * x.shape[0] if self.world > 1 else -1,
+                                          per_step=self.reward_mode == "per_step")
         self.last_stats = (nll, R_s, R_g)
         return loss

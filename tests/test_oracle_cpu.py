@@ -266,3 +266,29 @@ def test_logmel80_oracle_bank_properties():
     assert lm.shape == (80, 16) and lm.max() - lm.min() <= 80.0 + 1e-9
     p = fr.power_spectrogram(w) @ fb
     np.testing.assert_allclose(lm.T, np.maximum(10 * np.log10(np.maximum(p, 1e-10)), (10 * np.log10(np.maximum(p, 1e-10))).max() - 80.0))
+
+
+def test_step_rewards_and_reward_to_go_properties():
+    """The per-step rewards of policy_grad.py:10-15 (intent) telescope to |y| - ED(y, yhat); the per-frame reward-to-go used by the
+    "per_step" reward mode is their suffix sum laid on the frames where the characters start."""
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        T, V = int(rng.integers(5, 60)), 6
+        path = rng.integers(0, V, size=T)
+        path[rng.random(T) < 0.4] = 0
+        y = list(rng.integers(1, V, size=int(rng.integers(0, 12))))
+        G, seq, rho = decode_ref.reward_to_go(path, y)
+        ed = decode_ref.edit_dist(y, seq)[0]
+        assert rho == [decode_ref.edit_dist(y, seq[:j - 1])[0] - decode_ref.edit_dist(y, seq[:j])[0] for j in range(1, len(seq) + 1)]
+        assert G[0] == len(y) - ed and len(rho) == len(seq)
+        starts = [t for t in range(T) if path[t] != 0 and (t == 0 or path[t] != path[t - 1])]
+        drop = np.append(G[:-1] - G[1:], G[-1])                   # what frame t's own character earns
+        want = np.zeros(T); want[starts] = rho
+        np.testing.assert_array_equal(drop, want)
+        r = decode_ref.step_rewards(y, seq)
+        if len(seq) >= 2:
+            assert r[0] == rho[0] + rho[1] and r[1:len(seq) - 1] == rho[2:] and r[-1] == 0      # slices past the end saturate
+            assert sum(r) == len(y) - ed
+        # frames before the first character all carry the whole reward; frames after the last start carry none
+        first = next((t for t, k in enumerate(path) if k != 0), T)
+        assert np.all(G[:first + 1] == G[0])

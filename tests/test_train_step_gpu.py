@@ -61,6 +61,88 @@ def test_pg_ctc_loss_vs_oracle(lam):
     assert rel_err(lg.grad.cpu(), want_grad) < 1e-3
 
 
+def oracle_step_coefs(logits, in_len, targets, tg_len, lam, paths):
+    """(T,B) per-frame coefficients of the "per_step" reward mode, from the oracle's character-by-character reward-to-go."""
+    T, B, V = logits.shape
+    greedy = np.argmax(logits, axis=2)
+    coef = np.zeros((T, B))
+    for b in range(B):
+        y = list(targets[b][:tg_len[b]])
+        Gs, _, _ = decode_ref.reward_to_go(paths[:in_len[b], b], y)
+        Gg, _, _ = decode_ref.reward_to_go(greedy[:in_len[b], b], y)
+        coef[:in_len[b], b] = lam * (Gs - Gg) / (max(int(tg_len[b]), 1) * B)
+    return coef
+
+
+@pytest.mark.parametrize("shape", [(200, 4, 29, 20), (70, 3, 7, 9), (1000, 32, 29, 100)])
+def test_pg_ctc_loss_per_step_rewards_vs_oracle(shape):
+    """reward_mode "per_step": the per-step rewards of policy_grad.py:10-15 in the gradient, as per-frame rewards-to-go against the
+    greedy path's (pgasr_pg_step_coefs): coefficients, objective value and gradient against the fp64 oracle; frame 0 carries the
+    utterance-level coefficient; headline shape included."""
+    from policy_gradient_asr_amd import hipops
+    from policy_gradient_asr_amd.loss import pg_ctc_loss
+    T, B, V, L = shape
+    g = torch.Generator().manual_seed(T + B)
+    logits = torch.randn(T, B, V, generator=g) * 2
+    logits[:, :, 0] += 2.5
+    targets = torch.randint(1, V, (B, L), generator=g, dtype=torch.int32)
+    in_len = torch.randint(T // 2, T + 1, (B,), generator=g, dtype=torch.int32); in_len[0] = T
+    tg_len = torch.randint(1, L + 1, (B,), generator=g, dtype=torch.int32); tg_len[0] = L
+    if B > 2:
+        tg_len[2] = 0                                                      # an empty transcript: |y| = 0, rewards = -insertions
+    lam = 0.7
+    lg = logits.to(DEV).requires_grad_(True)
+    loss, nll, R_s, R_g = pg_ctc_loss(lg, in_len.to(DEV), targets.to(DEV), tg_len.to(DEV), lam=lam, seed=31, offset=2, per_step=True)
+    loss.backward()
+    ln, il, tn, tl = logits.double().numpy(), in_len.numpy(), targets.numpy(), tg_len.numpy()
+    paths, _, _ = decode_ref.sample_paths(ln, seed=31, offset=2)
+    coef = oracle_step_coefs(ln, il, tn, tl, lam, paths)
+    # the device's coefficients, from the same pieces the loss uses
+    lp = hipops.log_softmax_rows(logits.to(DEV))
+    greedy_d, sample_d = hipops.frame_argmax_sample(lp, seed=31, offset=2)
+    np.testing.assert_array_equal(sample_d.cpu().numpy(), paths)
+    both = torch.stack((greedy_d, sample_d), dim=0)
+    tokens, tok_len = hipops.ctc_collapse(both, in_len.to(DEV), blank=0)
+    dist, prefix = hipops.edit_distance(targets.to(DEV).repeat(2, 1), tg_len.to(DEV).repeat(2), tokens.view(2 * B, T), tok_len.view(2 * B), want_prefix=True)
+    got = hipops.pg_step_coefs(both, in_len.to(DEV), prefix, tok_len.view(2 * B), tg_len.to(DEV), lam, 1.0 / B)
+    np.testing.assert_allclose(got.cpu().numpy(), coef, rtol=1e-6, atol=1e-9)
+    _, _, coef_utt, _ = hipops.pg_rewards(dist, tg_len.to(DEV), lam, 1.0 / B)
+    np.testing.assert_allclose(got[0].cpu().numpy(), coef_utt.cpu().numpy(), rtol=1e-6, atol=1e-9)      # frame 0 = the utterance coefficient
+    assert float(got.abs().sum()) > 0
+    # objective and gradient
+    nll_o, g_ctc = ctc_ref.ctc_loss_and_grad(ln, tn, il, tl)
+    scale = 1.0 / (np.maximum(tl, 1) * B)
+    lpo = ctc_ref.log_softmax(ln, axis=2)
+    picked = np.take_along_axis(lpo, paths[..., None], axis=2)[..., 0]
+    finite = np.isfinite(nll_o)
+    want_loss = (np.where(finite, nll_o, 0.0) * scale).sum() - (coef * picked).sum()
+    want_grad = g_ctc * scale[None, :, None] + decode_ref.reinforce_grad(ln, paths, coef, il)
+    if finite.all():
+        assert abs(float(loss) - want_loss) / abs(want_loss) < 1e-4
+    assert rel_err(lg.grad.cpu(), want_grad) < 1e-3
+    with pytest.raises(ValueError):
+        pg_ctc_loss(lg, in_len.to(DEV), targets.to(DEV), tg_len.to(DEV), lam=lam, beam=4, per_step=True)
+
+
+def test_per_step_reward_mode_trains():
+    """A trainer in reward_mode "per_step" takes steps (finite loss, applied updates) and its gradient differs from the utterance mode's."""
+    from policy_gradient_asr_amd.model import Seq2Seq
+    from policy_gradient_asr_amd.train_step import PolicyGradientTrainer
+    B, F, T, V, L = 4, 80, 200, 29, 20
+    x, targets, fmask, tmask = _make(B, F, T, V, L, [200, 170, 200, 120], [20, 15, 20, 9], 5)
+    grads = {}
+    for mode in ("utterance", "per_step"):
+        torch.manual_seed(0)
+        m = Seq2Seq(V, n_feats=F).to(DEV).train()
+        tr = PolicyGradientTrainer(m, lr=1e-3, lam=1.0, seed=3, reward_mode=mode)
+        loss = tr.step(x.to(DEV), targets.to(DEV), fmask.to(DEV), tmask.to(DEV))
+        assert np.isfinite(float(loss)) and tr.applied_steps() == 1
+        grads[mode] = torch.cat([p.grad.flatten() for p in m.parameters()]).cpu()
+    assert float((grads["utterance"] - grads["per_step"]).abs().max()) > 0
+    with pytest.raises(ValueError):
+        PolicyGradientTrainer(m, reward_mode="per_step", reward_decoder="beam")
+
+
 def _make(B, F, T, V, L, lens, tlens, seed):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, F, T, generator=g)
