@@ -103,6 +103,14 @@ int pgasr_pg_step_coefs(const int32_t* paths, const int32_t* input_lengths, cons
                         float lam, float inv_global_batch, float* coef, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * A4  the CTC head as one kernel (model.py:52-55 as the build's Seq2Seq uses it): logits = x W^T + bias, log_probs = log_softmax.
+ *   x (rows, K) fp32 with row stride ldx, W (V, K) row-major, bias (V) or NULL; logits / log_probs (rows, V), either may be NULL.
+ *   Exact fp32 arithmetic (v_mfma_f32_32x32x2_f32) in every precision mode; one pass over x.  V <= 32, K % 64 == 0, K <= 1024.
+ * ---------------------------------------------------------------------------------------- */
+int pgasr_head_logsoftmax(const float* x, long long rows, int K, int ldx, const float* W, const float* bias, int V,
+                          float* logits, float* log_probs, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * A9 / A12  per-frame best label and sampled label.
  *   scores (T,B,V) fp32 logits or log-probs (softmax is shift invariant).
  *   greedy_path[t,b] = argmax_v scores[t,b,v], first max wins  (oracle: numpy argmax)

@@ -31,6 +31,7 @@ SIGNATURES = {
     "pgasr_pg_rewards": (C.c_int, [c_i32p, c_i32p, C.c_int, C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_ptr]),
     "pgasr_pg_loss_value": (C.c_int, [c_f32p, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       c_f32p, c_ptr]),
+    "pgasr_head_logsoftmax": (C.c_int, [c_f32p, C.c_longlong, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, c_f32p, c_ptr]),
     "pgasr_pg_step_coefs": (C.c_int, [c_i32p, c_i32p, c_i32p, C.c_int, c_i32p, c_i32p, C.c_int, C.c_int, C.c_int,
                                       C.c_float, C.c_float, c_f32p, c_ptr]),
     "pgasr_frame_argmax_sample": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.c_int,

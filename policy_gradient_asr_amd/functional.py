@@ -293,6 +293,29 @@ class LinearFn(torch.autograd.Function):
         return dx.view(ctx.shp), dW, db
 
 
+class HeadFn(torch.autograd.Function):
+    """(logits, log_probs) = the CTC head and its log-softmax from ONE kernel (``pgasr_head_logsoftmax``: exact fp32, one pass over x).
+    ``log_probs`` is handed to the fused loss as a by-product (not differentiable: the loss's gradient arrives through ``logits``,
+    d/dlogits of a function of log_softmax(logits)); the backward is LinearFn's."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        shp = x.shape
+        x2 = x.contiguous().view(-1, shp[-1])
+        weight = weight.contiguous()
+        logits, lp = hipops.head_logsoftmax(x2, weight, bias.contiguous())
+        ctx.save_for_backward(x2, weight)
+        ctx.shp = shp
+        ctx.param_refs = (weight, bias)
+        lp = lp.view(*shp[:-1], -1)
+        ctx.mark_non_differentiable(lp)
+        return logits.view(*shp[:-1], -1), lp
+
+    @staticmethod
+    def backward(ctx, dy, _dlp=None):
+        return LinearFn.backward(ctx, dy)
+
+
 class LogSoftmaxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits):

@@ -216,6 +216,27 @@ def pg_loss_value(log_probs, path, input_lengths, nll, utt_scale, pg_coef):
     return terms
 
 
+FUSED_HEAD = _os_environ_get("PGASR_FUSED_HEAD", "1") != "0"
+
+
+def head_logsoftmax_ok(K, V):
+    return FUSED_HEAD and V <= 32 and K % 64 == 0 and K <= 1024
+
+
+def head_logsoftmax(x, weight, bias, want_logits=True):
+    """x (rows,K) @ weight (V,K)^T + bias -> (logits or None, log_probs), both (rows,V): the CTC head as one exact-fp32 kernel."""
+    lib = _lib.load()
+    _req(x, torch.float32, "x"); _req(weight, torch.float32, "weight"); _req(bias, torch.float32, "bias")
+    rows, K = x.shape
+    V = weight.shape[0]
+    logits = torch.empty(rows, V, dtype=torch.float32, device=x.device) if want_logits else None
+    lp = torch.empty(rows, V, dtype=torch.float32, device=x.device)
+    with _timed("head_logsoftmax"):
+        st = lib.pgasr_head_logsoftmax(_p(x), rows, K, x.stride(0), _p(weight), _p(bias), V, _p(logits), _p(lp), _stream())
+    _lib.check(st, "pgasr_head_logsoftmax")
+    return logits, lp
+
+
 def pg_step_coefs(paths, input_lengths, prefix_dist, token_lengths, target_lengths, lam, inv_global_batch, blank=0):
     """Per-frame REINFORCE coefficients (T,B) from the per-step rewards (policy_grad.py:10-15; include/pgasr_hip.h):
     paths (2,T,B) greedy then sampled frame labels, prefix_dist (2B, P) / token_lengths (2B) of their collapsed forms."""

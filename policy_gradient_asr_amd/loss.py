@@ -54,12 +54,16 @@ class PGCTCLossFn(torch.autograd.Function):
     unit_seed_ptr = None
     unit_hits = 0              # how often the shortcut was taken (tests)
     @staticmethod
-    def forward(ctx, logits, in_len, targets, tg_len, lam, seed, offset, global_batch, blank, beam=0, sample_base=-1, per_step=False):
+    def forward(ctx, logits, in_len, targets, tg_len, lam, seed, offset, global_batch, blank, beam=0, sample_base=-1, per_step=False,
+                log_probs=None):
         T, B, V = logits.shape
         if per_step and beam > 0:
             raise ValueError("per-step rewards need the frame-aligned greedy baseline (beam = 0)")
         dev = logits.device
-        lp = hipops.log_softmax_rows(logits.contiguous())
+        # log-probs the head kernel already produced for exactly this tensor (model.Seq2Seq.logits), else one pass over the logits
+        lp = log_probs
+        if lp is None or lp.shape != logits.shape or not lp.is_contiguous():
+            lp = hipops.log_softmax_rows(logits.contiguous())
         # The alpha/beta lattice (96 workgroups, a serial chain of T frames, ~0.27 ms at T=1000) is the long pole of this
         # section and stays on the CALLING stream; sampling, collapse, (beam search,) edit distance and the reward
         # arithmetic (~0.13 ms with the greedy baseline) run beside it on a side stream and are joined before the gradient
@@ -106,18 +110,21 @@ class PGCTCLossFn(torch.autograd.Function):
         (grad,) = ctx.saved_tensors
         if PGCTCLossFn.unit_seed_ptr is not None and g.data_ptr() == PGCTCLossFn.unit_seed_ptr and g.numel() == 1:
             PGCTCLossFn.unit_hits += 1
-            return (grad,) + (None,) * 11
-        return (grad * g,) + (None,) * 11
+            return (grad,) + (None,) * 12
+        return (grad * g,) + (None,) * 12
 
 
 def pg_ctc_loss(logits, in_len, targets, tg_len, lam=1.0, seed=0, offset=0, global_batch=None, blank=0, beam=0, sample_base=-1,
-                per_step=False):
+                per_step=False, log_probs=None):
     """beam > 0: the baseline reward comes from the prefix-beam-search hypothesis of that width (see PGCTCLossFn).
     sample_base >= 0 (data parallel): index of this shard's first utterance in the global batch; the sampled paths are
-    then those of the single-process global batch with the same seed."""
+    then those of the single-process global batch with the same seed.
+    log_probs: log_softmax(logits) if the caller already has it (the head kernel's by-product, ``logits.log_probs`` of
+    Seq2Seq.logits -- picked up from that attribute when not given)."""
     B = logits.shape[1]
     return PGCTCLossFn.apply(logits, in_len, targets, tg_len, float(lam), int(seed), int(offset),
-                             int(global_batch or B), int(blank), int(beam), int(sample_base), bool(per_step))
+                             int(global_batch or B), int(blank), int(beam), int(sample_base), bool(per_step),
+                             log_probs if log_probs is not None else getattr(logits, "log_probs", None))
 
 
 class CTCLoss(nn.Module):

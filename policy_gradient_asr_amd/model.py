@@ -161,11 +161,16 @@ class Seq2Seq(nn.Module):
     def logits(self, x, fmask, lengths=None):
         """(T,B,V) pre-softmax scores and int32 lengths -- what the fused loss consumes."""
         h, lengths = self.encoder.forward_time_major(x, fmask, lengths)
+        if hipops.head_logsoftmax_ok(self.head.in_features, self.head.out_features):
+            # head + log-softmax in one kernel; the log-probs ride along for the fused loss (pg_ctc_loss takes them from the attribute)
+            z, lp = Fh.HeadFn.apply(h, self.head.weight, self.head.bias)
+            z.log_probs = lp
+            return z, lengths
         return Fh.LinearFn.apply(h, self.head.weight, self.head.bias), lengths
 
     def forward(self, x, t, fmask, device=None):
         z, _ = self.logits(x, fmask)
-        return Fh.LogSoftmaxFn.apply(z)
+        return Fh.LogSoftmaxFn.apply(z)        # differentiable log-probs for callers outside the fused loss
 
 
 # ------------------------------------------------------------------------------------------

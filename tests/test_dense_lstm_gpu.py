@@ -143,6 +143,28 @@ def test_gemm_x6w_six_product(M, N, K, with_bias, with_dact):
     assert hipops.gemm_x3w_ok(M, N, K, planes=3) and not hipops.gemm_x3w_ok(M, N + 128, K, planes=3) and not hipops.gemm_x3w_ok(M, N, K + 8, planes=3)
 
 
+@pytest.mark.parametrize("M,K,V", [(32000, 512, 29), (77, 64, 7), (33, 256, 32), (1, 128, 1), (4000, 1024, 29)])
+def test_head_logsoftmax_kernel_vs_fp64(M, K, V):
+    """pgasr_head_logsoftmax (A4: Linear + log_softmax in one exact-fp32 kernel): logits and log-probs against fp64, ragged row
+    counts (the tail block), the limits V = 32 / K = 1024, and what it refuses."""
+    from policy_gradient_asr_amd import hipops, _lib
+    g = torch.Generator().manual_seed(M + K + V)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(V, K, generator=g) * 0.1
+    b = torch.randn(V, generator=g)
+    want = x.double() @ W.double().t() + b.double()
+    want_lp = torch.log_softmax(want, dim=1)
+    z, lp = hipops.head_logsoftmax(x.to(DEV), W.to(DEV), b.to(DEV))
+    assert rel_err(z.cpu(), want) < 2e-6
+    assert float((lp.cpu().double() - want_lp).abs().max()) < 2e-5 * max(1.0, float(want_lp.abs().max()))
+    z2, lp2 = hipops.head_logsoftmax(x.to(DEV), W.to(DEV), b.to(DEV), want_logits=False)
+    assert z2 is None and torch.equal(lp2, lp)
+    assert torch.equal(hipops.log_softmax_rows(z.view(1, M, V)).view(M, V), lp) or float((hipops.log_softmax_rows(z.view(1, M, V)).view(M, V) - lp).abs().max()) < 1e-5
+    assert not hipops.head_logsoftmax_ok(K + 8, V) and not hipops.head_logsoftmax_ok(K, 33)
+    with pytest.raises(_lib.PgasrError):
+        hipops.head_logsoftmax(x.to(DEV), torch.randn(33, K).to(DEV), torch.zeros(33).to(DEV))
+
+
 @pytest.mark.parametrize("busy_mask", [0x00, 0x0F, 0xA5, 0xFE, 0xFF])
 def test_gemm_queue_mode_is_placement_independent(busy_mask):
     """Queue mode (pgasr_gemm_f32 xcc_busy != NULL): whichever XCDs are declared busy -- none, half, all but
