@@ -1,4 +1,5 @@
-"""Soak: many train steps, then every LSTM workspace's error word must still be 0 and the loss finite (development aid)."""
+"""Soak: many train steps, then every LSTM workspace's error word must still be 0 and the loss finite (development aid).
+PREC=f32|bf16x3, REWARD_MODE=utterance|per_step, argv[1] = steps."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -9,7 +10,7 @@ from bench import synth_batch, V, F
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(dev); m.train()
-tr = PolicyGradientTrainer(m, seed=1)
+tr = PolicyGradientTrainer(m, seed=1, precision=os.environ.get("PREC") or None, reward_mode=os.environ.get("REWARD_MODE", "utterance"))
 batch = [v.to(dev) for v in synth_batch(1)]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 t0 = time.perf_counter()
