@@ -115,6 +115,9 @@ struct LstmArgs {
     long long* stamps;       // diagnostic build only (-DPGASR_LSTM_STAMPS)
 };
 
+#ifndef PGASR_PUBLISH_BRANCHFREE
+#define PGASR_PUBLISH_BRANCHFREE 1
+#endif
 #ifdef PGASR_LSTM_STAMPS
 // Diagnostic build: wave 0 of every workgroup accumulates, in registers, the cycles between consecutive stamps (segment
 // ending at `slot`); one store per workgroup at the end (member 5 of cluster 0 is read by tools/dev/tools_stamps.py).  No memory
@@ -859,6 +862,10 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     unsigned char* xb = a.xbuf + (size_t)cl * (2 * SLOT);
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)(2 * SLOT), 0x00020000);
     const bool same_xcd = cluster_same_xcd(a, cl, g, tid, s_same, s_abort);
+    // publish descriptors: the plain form lands in this XCD's L2 (cluster verified to share it), the write-through form is for
+    // a cluster spread over XCDs; the one that does not apply has an empty range, so stores through it are dropped
+    __amdgpu_buffer_rsrc_t rs_same = __builtin_amdgcn_make_buffer_rsrc(xb, 0, same_xcd ? (int)(2 * SLOT) : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_far = __builtin_amdgcn_make_buffer_rsrc(xb, 0, same_xcd ? 0 : (int)(2 * SLOT), 0x00020000);
 
     const int bidx = bg * 16 + pn;
     const int len = (bidx < B) ? a.lengths[bidx] : 0;
@@ -960,6 +967,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
         }
         if (nslab && !aborted) publish();       // the last slab (k_pub == number of slabs here)
     } else {
+        STAMP_DECL;        // diagnostic build: 0 loop top + pre-poll cell work, 1 poll, 2 cell gradient + plane stores, 3 LDS barrier, 4 MFMA + publish
         auto compute_step = [&](const int step, const bool first) -> int {
             const int t = step_t(step);
             float4 d = make_float4(0, 0, 0, 0);
@@ -975,6 +983,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
             const float k_c = go * (1.f - tc * tc);          // d(dh) -> d(c)
             const float k_i = gg * gi * (1.f - gi), k_f = cp * gf * (1.f - gf), k_g = gi * (1.f - gg * gg), k_o = tc * go * (1.f - go);
             float dh_rec = carry;
+            STAMP(0);
             if (!first) {
                 // slot layout [src 16][dst 16][n 16][16 units]: what one member reads from one source is ONE contiguous KiB
                 // (a wave's load = 256 contiguous bytes), and what a wave publishes for one destination as well
@@ -1018,6 +1027,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
                 for (int s = 0; s < 16; ++s) sum += v[s];     // fixed order: reproducible
                 dh_rec += sum;
             }
+            STAMP(1);
             const float dh = dy + dh_rec;
             const float dct = dh * k_c + dc;
             d.x = dct * k_i;
@@ -1037,7 +1047,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
                     *reinterpret_cast<uint2*>(dst + 64 * pl) = make_uint2(px[pl] | ((unsigned)py[pl] << 16), pz[pl] | ((unsigned)pw[pl] << 16));
             }
             rdg[step & 1][tid] = d;      // written to HBM by the storer wave after the barrier
+            STAMP(2);
             LDS_BARRIER();
+            STAMP(3);
             const int aborted = LDS_FLAG_GET(s_abort);       // read behind the barrier, used at the end of the step
             {
                 // (also after the last step: nobody reads that slot, and lstm_prepare_kernel resets it)
@@ -1076,17 +1088,30 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
 #ifdef PGASR_LSTM_DIAG
                         if (no_publish) continue;
 #endif
-                        if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 0);
-                        else          __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 16);
+                        if constexpr (PGASR_PUBLISH_BRANCHFREE && NP == 3) {
+                            // both forms are issued, one of them against a descriptor with an EMPTY range (the hardware drops it)
+                            // instead of a wave-uniform if / else around each store (two taken branches per store, eight per step).
+                            // Measured (tools/dev/r4_branchfree.sh, library A/B, two rounds): three-plane backward sweep 1.279 ->
+                            // 1.259 ms alone, 4.74 -> 4.60 ms for the three of a step; the two-plane backward sweep LOSES (1.131 ->
+                            // 1.26 ms) and so do both forward sweeps (1.00 -> 1.10 / 1.33 -> 1.39 ms: 2 x NP two-byte stores per thread,
+                            // the dropped ones are not free) -- they keep the branches.
+                            __builtin_amdgcn_raw_buffer_store_b128(o, rs_same, off, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(o, rs_far, off, 0, 16);
+                        } else {
+                            if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 0);
+                            else          __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 16);
+                        }
                     }
                 }
             }
+            STAMP(4);
             return aborted;
         };
         if (T > 0 && !compute_step(0, true)) {
             for (int step = 1; step < T; ++step)
                 if (compute_step(step, false)) break;
         }
+        STAMP_FLUSH();
     }
     if (a.dbias_part) {
         // bias gradient for free: sum the per-cell running sums over the group's 16 utterances in a fixed order
