@@ -1075,6 +1075,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
                     for (int m2 = 0; m2 < 2; ++m2) acc[m2] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int i = 0; i < 2; ++i) mfma_planes_pair<NP>(W[2 * half][i], W[2 * half + 1][i], Dp[i], acc);
+                    if (half == 0) STAMP(5); else STAMP(7);
 #pragma unroll
                     for (int m2 = 0; m2 < 2; ++m2) {
                         const int mt = 2 * half + m2;
@@ -1102,6 +1103,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
                             else          __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, off, 0, 16);
                         }
                     }
+                    if (half == 0) STAMP(6);
                 }
             }
             STAMP(4);

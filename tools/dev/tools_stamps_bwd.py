@@ -14,7 +14,8 @@ prec = os.environ.get("PREC", "f32")
 hipops.set_precision(prec)
 lib = _lib.load()
 T, B = bench.T, bench.B_PER_GPU
-NAMES = {0: "loop top + pre-poll cell work", 1: "poll (partial sums valid)", 2: "cell gradient + plane stores", 3: "LDS barrier", 4: "MFMA + publish"}
+NAMES = {0: "loop top + pre-poll cell work", 1: "poll (partial sums valid)", 2: "cell gradient + plane stores", 3: "LDS barrier",
+         5: "fragment reads + first 2 tiles' MFMAs", 6: "their tag + stores", 7: "last 2 tiles' MFMAs", 4: "their tag + stores"}
 
 
 def report(tag, ws):
