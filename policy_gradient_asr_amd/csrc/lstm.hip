@@ -996,7 +996,8 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
                 // entering: hold the first poll back (x64 cycles).  Measured stand-alone 0: 1.61, 6: 1.59, 8: 1.55,
                 // 10: 1.52-1.57, 14: 1.61 us per step; train step 11.82 -> 11.64 ms with 10.  Re-measured after the dh-independent
                 // cell work moved in front of the poll: 6: 1.42, 8: 1.41, 10: 1.45, 12: 1.50, 14: 1.55; and again with the
-                // [src][dst][n][unit] slot layout (publishes land sooner): 0-4: 1.26-1.30, 6: 1.32, 8: 1.37, 10: 1.43 -> 2.  (The forward sweep
+                // [src][dst][n][unit] slot layout (publishes land sooner): 0-4: 1.26-1.30, 6: 1.32, 8: 1.37, 10: 1.43 -> 2.  Round 4, both
+                // plane counts (ms per sweep, NP = 3 / NP = 2): 0: 1.29 / 1.155, 2: 1.26 / 1.13, 4: 1.28 / 1.16, 6: 1.34 / 1.21.  (The forward sweep
                 // publishes 1 KiB per member and only loses from a delay: 1.15 -> 1.19 / 1.30 / 1.37 for 4 / 8 / 12.)
                 __builtin_amdgcn_s_sleep(PGASR_BWD_POLL_DELAY);
                 while (true) {
