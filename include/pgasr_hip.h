@@ -39,7 +39,7 @@ typedef enum pgasr_status {
 
 /* 4 (round 3): pgasr_adam_step(guards, applied), pgasr_lstm_pack_weights(planes), the feed phases, and the streamed order:
  * pgasr_lstm_wgrad_slabs, pgasr_lstm_layer_bwd_streamed, pgasr_lstm_wgrads_streamed(+_workspace_bytes), pgasr_stream_gate_sum. */
-#define PGASR_ABI_VERSION 6
+#define PGASR_ABI_VERSION 7
 
 int pgasr_abi_version(void);
 const char* pgasr_status_string(int status);
@@ -379,6 +379,10 @@ int pgasr_stream_gate(const unsigned* words, int count, int timeout_us, void* st
  * non-zero first word also opens the gate (the sweep has published, i.e. it is under way or already OVER: a gate that
  * comes late would otherwise sit out its whole time-out on counters that have gone back to zero). */
 int pgasr_stream_gate_sum(const unsigned* words, int count, int need, const unsigned* running, int timeout_us, void* stream);
+/* pgasr_stream_gate_sum that also says how it left (ABI 7): report[0] = 1 opened on the busy counters, 2 opened on a publication
+ * (`running`), 3 timed out; report[1] = microseconds the gate held the stream.  report may be NULL. */
+int pgasr_stream_gate_report(const unsigned* words, int count, int need, const unsigned* running, int timeout_us,
+                             unsigned* report, void* stream);
 /* One wave on `stream` waits (at most timeout_us <= 1e6) for words[0] != 0 and then writes words[1] = 1 if it saw it, else
  * 0.  Set words[0] from ANOTHER stream after this call: words[1] tells whether the two streams really run concurrently
  * (they do not under kernel-serialising profilers / launch-blocking modes / a single hardware queue).  The fed sweeps

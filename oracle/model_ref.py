@@ -69,9 +69,41 @@ def lstm_flat_weights(p):
     return flat
 
 
-def encoder_forward_torch(p, x, mask, packed=True, leaky_side=None, return_pre=False):
+def reverse_within_length(x, lengths):
+    """x (B,T,C), lengths (B,): frame t < len of utterance b <- frame len-1-t; frames past the length stay where they are."""
+    B, T = x.shape[0], x.shape[1]
+    t = torch.arange(T)[None, :]
+    L = lengths.to(torch.int64)[:, None]
+    idx = torch.where(t < L, L - 1 - t, t)
+    return torch.gather(x, 1, idx[:, :, None].expand_as(x))
+
+
+def blstm_layer_packed_equivalent(x, lengths, w):
+    """One bidirectional LSTM layer with the PACKED-sequence semantics of model.py:52-55 (the reverse direction starts at each
+    utterance's own last valid frame; outputs past the length are exactly 0) WITHOUT torch's packed-sequence path, which on the
+    CPU takes minutes at T = 1000: the forward direction is an ordinary LSTM over the padded batch (padding comes after the valid
+    frames and cannot reach them), the reverse direction the same LSTM over each utterance reversed within its own length; outputs
+    are masked and the reverse ones flipped back.  The same arithmetic per valid frame as nn.LSTM(bidirectional) on a
+    PackedSequence -- checked against it (outputs and gradients) and against the reference's own Encoder outputs in
+    tests/test_oracle_cpu.py.  x (B,T,I); w: the eight tensors weight_ih, weight_hh, bias_ih, bias_hh (forward), then reverse."""
+    B, T, I = x.shape
+    Hd = w[1].shape[1]
+    mask = (torch.arange(T)[None, :] < lengths.to(torch.int64)[:, None])[:, :, None].to(x.dtype)
+    outs = []
+    for d in (0, 1):
+        inp = x if d == 0 else reverse_within_length(x, lengths)
+        cell = torch.nn.LSTM(I, Hd, 1, batch_first=True).to(x.dtype)
+        names = ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")
+        o, _ = torch.func.functional_call(cell, dict(zip(names, w[4 * d:4 * d + 4])), (inp,))
+        o = o * mask
+        outs.append(o if d == 0 else reverse_within_length(o, lengths))
+    return torch.cat(outs, dim=2)
+
+
+def encoder_forward_torch(p, x, mask, packed=True, leaky_side=None, return_pre=False, fast_packed=False):
     """p: dict of tensors; x (B,F,T); mask (B,T) 1/0 -> (B,T,512).
     Eval mode (no dropout).  model.py:47-56.
+    fast_packed (with packed): the packed semantics through ``blstm_layer_packed_equivalent`` (full-size ragged batches).
     leaky_side (B,T,512) bool: which side of leaky_relu (model.py:50) each pre-activation is put on, instead of its own
     sign -- a DISCRETE choice, like an arg-max: a full-size parity test that shares the discrete choices of the device
     path (tests/test_train_step_gpu.py) passes the device's sides after counting how many differ from the oracle's own.
@@ -85,7 +117,12 @@ def encoder_forward_torch(p, x, mask, packed=True, leaky_side=None, return_pre=F
     lstm.eval()
     # run the module with OUR tensors as its parameters so gradients flow back to ``p``
     sd = {k[len("blstm."):]: v for k, v in p.items() if k.startswith("blstm.")}
-    if packed:
+    if packed and fast_packed:
+        out = h
+        for l in range(N_LAYERS):
+            out = blstm_layer_packed_equivalent(out, lengths, [sd[f"{k}_l{l}{sfx}"] for sfx in ("", "_reverse")
+                                                               for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")])
+    elif packed:
         pk = pack_padded_sequence(h, lengths, enforce_sorted=False, batch_first=True)
         out, _ = torch.func.functional_call(lstm, sd, (pk,))
         out, _ = pad_packed_sequence(out, total_length=T, batch_first=True)

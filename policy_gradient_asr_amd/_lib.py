@@ -82,6 +82,7 @@ SIGNATURES = {
     "pgasr_lstm_status": (C.c_int, [c_ptr, C.c_size_t, C.c_int, C.c_int, c_ptr]),
     "pgasr_stream_gate": (C.c_int, [c_ptr, C.c_int, C.c_int, c_ptr]),
     "pgasr_stream_gate_sum": (C.c_int, [c_ptr, C.c_int, C.c_int, c_ptr, C.c_int, c_ptr]),
+    "pgasr_stream_gate_report": (C.c_int, [c_ptr, C.c_int, C.c_int, c_ptr, C.c_int, c_ptr, c_ptr]),
     "pgasr_stream_probe": (C.c_int, [c_ptr, C.c_int, c_ptr]),
     "pgasr_lstm_layer_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_ptr, c_i32p, C.c_int, C.c_int, C.c_int,
                                        c_f32p, C.c_float, C.c_uint64, C.c_uint32, c_ptr, C.c_size_t, c_ptr]),
@@ -136,7 +137,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.pgasr_abi_version() != 6:
+    if lib.pgasr_abi_version() != 7:
         raise PgasrError("libpgasr_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -338,6 +338,21 @@ __device__ __forceinline__ unsigned row_allmax(unsigned v) {
     x = dpp_u32<0x121>(v); v = v > x ? v : x;
     return v;
 }
+// the same over all 64 lanes with VALU operations only (gfx950's row swaps): nothing goes through the scalar unit, so the
+// result can feed the next vector instruction of a round's chain directly
+__device__ __forceinline__ unsigned wave_allmax_valu(unsigned v) {
+    v = row_allmax(v);
+    auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);      // rows (0,1) and (2,3) meet
+    v = a[0] > a[1] ? a[0] : a[1];
+    auto c = __builtin_amdgcn_permlane32_swap(v, v, false, false);      // the two halves meet
+    return c[0] > c[1] ? c[0] : c[1];
+}
+// row 0's value of v in all four rows
+__device__ __forceinline__ unsigned row0_to_all(unsigned v) {
+    auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    auto c = __builtin_amdgcn_permlane32_swap(a[0], a[0], false, false);
+    return c[0];
+}
 __device__ __forceinline__ unsigned wave_allmax(unsigned v) {
     v = row_allmax(v);
     const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
@@ -457,32 +472,77 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
         // no wait on the K-round chain)
 
         // ---- K rounds: pop the winners in rank order ----
-        // (Measured and not kept: TWO winners per round from one all-reduce over (first, second) pairs of high words -- exact,
-        // all tests green, but the pair combine is 6 VALU operations per DPP step against one fused v_max_u32_dpp, and
-        // 8 readlanes against 4: 5.28 against 4.89 us per frame at beam 16, 2.82 against 2.68 at beam 5.)
+        // Round 5: a round used to be all-reduce (4 DPP) -> 4 readlanes -> 3 scalar max -> compare -> ballot -> ffs -> readlane of the
+        // winner's low word -> 16 moves under a one-lane exec mask, ~420 cycles of mostly scalar-unit round trips, sixteen times per
+        // frame (60 % of it).  Now the chain of a round is vector-only: all-reduce of the lists' HIGH words (4 DPP + 2 row swaps),
+        // compare, and a shift of the eight high words of the lanes that won (v_cndmask on the compare's mask).  What a round
+        // leaves behind -- which lane won (s_ff1 of the mask -> v_writelane into lane r) and a won-bit per lane -- is scalar work off
+        // the chain; the winners' identities are put together AFTER the rounds: lane r fetches its winner lane's won-bits and sort
+        // permutation with two ds_bpermute and finds the slot as the (number of earlier wins of that lane)-th of its sorted list.
+        // A round in which two lanes share the maximal high word (equal to 2^-20 relative: ~1e-4 of the frames on real scores;
+        // always with -inf scores) makes both pop: the scalar tallies disagree and the frame is redone by the exact loop below.
+        // (Measured and not kept in round 4: TWO winners per round from one all-reduce over (first, second) pairs of high words.)
         unsigned packed = 0u;
         int nnew = 0;
-        for (int r = 0; r < K; ++r) {
-            const unsigned long long head = k[0];
-            const unsigned hh = (unsigned)(head >> 32);
-            const unsigned smax = wave_allmax(hh);
-            if (smax == 0u) break;
-            unsigned long long m = __ballot(hh == smax);
-            if (__popcll(m) != 1) {
-                const unsigned ll = (hh == smax) ? (unsigned)head : 0u;
-                const unsigned smaxlo = wave_allmax(ll);
-                m = __ballot(hh == smax && (unsigned)head == smaxlo);
-            }
-            const int wl = __ffsll((long long)m) - 1;
-            const unsigned wlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)head, wl);
-            const unsigned pk = ((unsigned)(wl >> 4) << 7) | (wlo & 0x7Fu);
-            if (j == r) packed = pk;
-            if (lane == wl) {
+        {
+            unsigned hq[8];
+            unsigned perm = 0u;                    // slot of the d-th key of the sorted list, 3 bits each
 #pragma unroll
-                for (int d = 0; d < 7; ++d) k[d] = k[d + 1];
-                k[7] = 0ull;
+            for (int d = 0; d < 8; ++d) { hq[d] = (unsigned)(k[d] >> 32); perm |= (((unsigned)k[d] >> 4) & 7u) << (3 * d); }
+            unsigned won = 0u, wl_of = 0u;
+            int pops = 0, rounds = 0;
+#define SB_ROUND(r)                                                                                                  \
+            if (K > (r)) {                                                                                               \
+                const unsigned hh = hq[0];                                                                               \
+                const unsigned smax = wave_allmax_valu(hh);                                                              \
+                const bool win = (hh == smax) && (smax != 0u);                                                           \
+                const unsigned long long m = __ballot(win);                                                              \
+                pops += __popcll(m); rounds += (m != 0ull) ? 1 : 0;                                                      \
+                {   /* lane r of wl_of := the winner lane (a scalar); v_writelane has no builtin in this compiler */     \
+                    const int wls = __ffsll((long long)m) - 1;                                                           \
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(wl_of) : "s"(wls), "n"(r));                         \
+                }                                                                                                        \
+                won |= win ? (1u << (r)) : 0u;                                                                           \
+                _Pragma("unroll") for (int d = 0; d < 7; ++d) hq[d] = win ? hq[d + 1] : hq[d];                           \
+                hq[7] = win ? 0u : hq[7];                                                                                \
             }
-            ++nnew;
+            SB_ROUND(0) SB_ROUND(1) SB_ROUND(2) SB_ROUND(3) SB_ROUND(4) SB_ROUND(5) SB_ROUND(6) SB_ROUND(7)
+            SB_ROUND(8) SB_ROUND(9) SB_ROUND(10) SB_ROUND(11) SB_ROUND(12) SB_ROUND(13) SB_ROUND(14) SB_ROUND(15)
+#undef SB_ROUND
+            static_assert(K_MAX == 16, "sixteen rounds are written out");
+            if (pops == rounds) {
+                nnew = rounds;
+                const unsigned wl = row0_to_all(wl_of);                       // lane (q, j): the winner lane of round j
+                const unsigned wwon = (unsigned)__shfl((int)won, (int)(wl & 63u), 64);
+                const unsigned wperm = (unsigned)__shfl((int)perm, (int)(wl & 63u), 64);
+                const int idx = __popc(wwon & ((1u << j) - 1u));               // how many rounds before round j that lane had won
+                const unsigned slot = (wperm >> (3 * idx)) & 7u;
+                packed = ((wl >> 4) << 7) | (slot << 4) | (wl & 15u);
+            } else {
+                // exact rounds on the full keys (ties between high words; rare)
+                for (int r = 0; r < K; ++r) {
+                    const unsigned long long head = k[0];
+                    const unsigned hh = (unsigned)(head >> 32);
+                    const unsigned smax = wave_allmax(hh);
+                    if (smax == 0u) break;
+                    unsigned long long m = __ballot(hh == smax);
+                    if (__popcll(m) != 1) {
+                        const unsigned ll = (hh == smax) ? (unsigned)head : 0u;
+                        const unsigned smaxlo = wave_allmax(ll);
+                        m = __ballot(hh == smax && (unsigned)head == smaxlo);
+                    }
+                    const int wl = __ffsll((long long)m) - 1;
+                    const unsigned wlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)head, wl);
+                    const unsigned pk = ((unsigned)(wl >> 4) << 7) | (wlo & 0x7Fu);
+                    if (j == r) packed = pk;
+                    if (lane == wl) {
+#pragma unroll
+                        for (int d = 0; d < 7; ++d) k[d] = k[d + 1];
+                        k[7] = 0ull;
+                    }
+                    ++nnew;
+                }
+            }
         }
 
         // ---- the new beam: entry r <- winner r ----

@@ -107,7 +107,7 @@ struct PgasrTn256Args {
                                 // the order a backward sweep completes them; A's rows are rows of the tensor at gate_base (gate may be nullptr)
     int* gate_err;              // set to 1 when a wait gives up (3 s)
 };
-bool pgasr_internal_tn256_ok(const PgasrTn256Args& a);
+bool pgasr_internal_tn256_ok(const PgasrTn256Args& a, int tk = 32);     // tk: rows per k-step of the kernel that will run (32: t256, 16: t6)
 int pgasr_internal_tn256_launch(PgasrTn256Args a, int masked_then_unmasked, hipStream_t st, const PgasrTn256Args* second = nullptr);
 // the same contract in the six-product arithmetic (three bf16 planes per operand, 16-deep steps): gemm_x6.hip
 int pgasr_internal_tn6_launch(PgasrTn256Args a, int masked_then_unmasked, hipStream_t st, const PgasrTn256Args* second = nullptr);

@@ -824,7 +824,8 @@ extern "C" int pgasr_lstm_wgrads_streamed(const float* dgates, const float* x, c
     PgasrTn256Args hh{dgates + (size_t)B * G, out, part_hh, 4 * H, H, (int)K_hh, G, 2 * H, (long long)4 * H - (long long)B * G,
                       (long long)B * 2 * H + H, 2, nslab, 0, 1.f,
                       (unsigned*)workspace, xcc_busy, 0, slab_done, dgates, T, B, (B + 15) / 16, 1, err_word};
-    if (!pgasr_internal_tn256_ok(ih) || !pgasr_internal_tn256_ok(hh)) return PGASR_ERR_UNSUPPORTED;
+    const int tk = planes == 3 ? 16 : 32;     // rows per k-step: the six-product kernel takes B % 16 == 0, the bf16x3 one B % 32 == 0
+    if (!pgasr_internal_tn256_ok(ih, tk) || !pgasr_internal_tn256_ok(hh, tk)) return PGASR_ERR_UNSUPPORTED;
     if (hipMemsetAsync(workspace, 0, 256, st) != hipSuccess) return PGASR_ERR_LAUNCH;
     const int rc = planes == 3 ? pgasr_internal_tn6_launch(ih, 1, st, &hh) : pgasr_internal_tn256_launch(ih, 1, st, &hh);
     if (rc != PGASR_OK) return rc;

@@ -648,10 +648,11 @@ int pgasr_internal_x3c_launch(const PgasrX3cArgs& a, hipStream_t st) {
     return PGASR_OK;
 }
 
-bool pgasr_internal_tn256_ok(const PgasrTn256Args& a) {
+bool pgasr_internal_tn256_ok(const PgasrTn256Args& a, int tk) {
+    if (tk != 16 && tk != 32) return false;
     if (a.gate && (!a.queue || !a.tslabs || a.gate_nbg <= 0 || a.gate_nbg > 32)) return false;
     if (a.tslabs) {
-        if (!a.gate_base || a.gate_T <= 0 || a.gate_B <= 0 || (a.gate_B % 32) || a.A < a.gate_base || (a.lda & 1)) return false;
+        if (!a.gate_base || a.gate_T <= 0 || a.gate_B <= 0 || (a.gate_B % tk) || a.A < a.gate_base || (a.lda & 1)) return false;
         if (a.splitk != pgasr_wslab_count(a.gate_T) || (size_t)a.gate_T * a.gate_B * a.lda * 4 >= ((size_t)1 << 31)) return false;
         // no empty slab: every batch's rows must reach into the first and the last 16 frames
         const long long first = (long long)((a.A - a.gate_base) / a.lda), last = first + a.K;
@@ -661,7 +662,7 @@ bool pgasr_internal_tn256_ok(const PgasrTn256Args& a) {
     const char* e = getenv("PGASR_TN_TILE");
     if (e && e[0] == '1' && e[1] == '2' && e[2] == '8') return false;
     if (!a.A || !a.B || !a.partial || a.M <= 0 || a.N <= 0 || a.K < 32 || a.batch <= 0 || a.splitk <= 0) return false;
-    if ((a.M % t256::TM) || (a.N % t256::TN) || (a.K % 32) || (!a.tslabs && (a.kper % 32)) || (a.lda & 3) || (a.ldb & 3)) return false;
+    if ((a.M % t256::TM) || (a.N % t256::TN) || (a.K % tk) || (!a.tslabs && (a.kper % 32)) || (a.lda & 3) || (a.ldb & 3)) return false;
     if ((a.sA & 3) || (a.sB & 3) || (((size_t)a.A) & 15) || (((size_t)a.B) & 15)) return false;
     if (!a.tslabs && (long long)(a.splitk - 1) * a.kper >= a.K) return false;        // no empty slab
     if ((size_t)a.M * a.N * 4 >= ((size_t)1 << 32)) return false;

@@ -629,7 +629,7 @@ __global__ __launch_bounds__(THREADS) void gemm_t6_kernel(PgasrTn256Args g0, Pga
         }
     }
     const int tbx = t2 % tx, tby = t2 / tx;
-    const int nk = (k_end - k_beg) / TK;               // >= 2 (pgasr_internal_tn256_ok: no empty slab, slabs are multiples of 32)
+    const int nk = (k_end - k_beg) / TK;               // >= 1 (pgasr_internal_tn256_ok: no empty slab, slabs are whole steps)
     const int m0 = tby * TM, n0 = tbx * TN;
     // wave w loads k-rows 2 w + j (j = 0, 1) of both operands: one 1-KB row per wave instruction
     const float* Ab = g.A + (size_t)bidx * g.sA + (size_t)(k_beg + 2 * w) * g.lda + m0 + 4 * lane;
@@ -912,9 +912,12 @@ extern "C" int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int 
 // ---- internal: the six-product TN kernel behind pgasr_lstm_wgrads_streamed(planes = 3) (same contract as pgasr_internal_tn256_launch) ----
 int pgasr_internal_tn6_launch(PgasrTn256Args a, int masked_then_unmasked, hipStream_t st, const PgasrTn256Args* second) {
     PgasrTn256Args b{};
-    if (!pgasr_internal_tn256_ok(a)) return PGASR_ERR_UNSUPPORTED;
+    // time slabs of a sweep over B % 16 == 0 utterances are whole 16-row steps of this kernel (dW_hh's shortened slab included);
+    // every other K partition keeps the 32-row rule of the shared dispatch
+    const int tk = a.tslabs ? t6::TK : 32;
+    if (!pgasr_internal_tn256_ok(a, tk)) return PGASR_ERR_UNSUPPORTED;
     if (second) {
-        if (!a.queue || second->splitk != a.splitk || !pgasr_internal_tn256_ok(*second)) return PGASR_ERR_UNSUPPORTED;
+        if (!a.queue || second->splitk != a.splitk || !pgasr_internal_tn256_ok(*second, tk)) return PGASR_ERR_UNSUPPORTED;
         b = *second;
     }
     const size_t lds = (size_t)t6::LDS_BYTES;

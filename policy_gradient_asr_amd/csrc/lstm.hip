@@ -1483,17 +1483,27 @@ extern "C" int pgasr_lstm_busy_offset(int B, int backward, size_t* offset) {
 namespace {
 // One wave that holds a stream back until a sweep has registered itself (any busy counter != 0) or the
 // time-out passes: gives "sweep first, GEMMs second" dispatch order across two streams.
+// report (optional, 2 words): how the gate left -- [0] = 1 opened on the busy counters, 2 opened on a publication (`running`),
+// 3 timed out; [1] = microseconds it held the stream.  Device evidence for tests (a host clock cannot tell a slow host from a
+// timed-out gate).
 __global__ void __launch_bounds__(64) stream_gate_kernel(const unsigned* words, int count, unsigned need, const unsigned* running,
-                                                         long long timeout_ticks) {
+                                                         long long timeout_ticks, unsigned* report) {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();
+    unsigned how = 0;
     for (;;) {
         unsigned sum = 0;
         for (int i = 0; i < count; ++i) sum += __hip_atomic_load(words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (running && __hip_atomic_load(running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) sum = need;
+        const bool published = running && __hip_atomic_load(running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
         POLL_FENCE();
-        if (sum >= need || wall_clock64() - t0 > timeout_ticks) break;
+        if (sum >= need) { how = 1; break; }
+        if (published) { how = 2; break; }
+        if (wall_clock64() - t0 > timeout_ticks) { how = 3; break; }
         __builtin_amdgcn_s_sleep(16);
+    }
+    if (report) {
+        __hip_atomic_store(report, how, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(report + 1, (unsigned)((wall_clock64() - t0) / 100), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 }  // namespace
@@ -1525,7 +1535,7 @@ extern "C" int pgasr_stream_probe(unsigned* words, int timeout_us, void* stream)
 
 extern "C" int pgasr_stream_gate(const unsigned* words, int count, int timeout_us, void* stream) {
     if (!words || count <= 0 || count > 64 || timeout_us < 0 || timeout_us > 100000) return PGASR_ERR_INVALID_ARG;
-    PGASR_LAUNCH_KERNEL(stream_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, count, 1u, (const unsigned*)nullptr, (long long)timeout_us * 100);
+    PGASR_LAUNCH_KERNEL(stream_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, count, 1u, (const unsigned*)nullptr, (long long)timeout_us * 100, (unsigned*)nullptr);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }
@@ -1534,8 +1544,13 @@ extern "C" int pgasr_stream_gate(const unsigned* words, int count, int timeout_u
 // `need` -- every cluster of the sweep has registered, i.e. all of its workgroups are resident -- since workgroups that poll for the
 // sweep's publications must not take CUs the sweep still needs.  Bounded like the other one (timeout_us <= 100000).
 extern "C" int pgasr_stream_gate_sum(const unsigned* words, int count, int need, const unsigned* running, int timeout_us, void* stream) {
+    return pgasr_stream_gate_report(words, count, need, running, timeout_us, nullptr, stream);
+}
+
+extern "C" int pgasr_stream_gate_report(const unsigned* words, int count, int need, const unsigned* running, int timeout_us,
+                                        unsigned* report, void* stream) {
     if (!words || count <= 0 || count > 64 || need <= 0 || timeout_us < 0 || timeout_us > 100000) return PGASR_ERR_INVALID_ARG;
-    PGASR_LAUNCH_KERNEL(stream_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, count, (unsigned)need, running, (long long)timeout_us * 100);
+    PGASR_LAUNCH_KERNEL(stream_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, count, (unsigned)need, running, (long long)timeout_us * 100, report);
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }

@@ -436,7 +436,7 @@ class BLSTMLayerFn(torch.autograd.Function):
         # run beside the NEXT layer's sweep, which left the first layer's in the tail of the step
         targets = [p.grad for p in ctx.param_refs]
         stream_own = (grad_overlap.enabled and STREAM_DW and all(t is not None and t.is_contiguous() for t in targets)
-                      and hipops.lstm_wgrads_ok(T, B, I) and hipops.lstm_fed_ok(T, B)
+                      and hipops.lstm_wgrads_ok(T, B, I, npl) and hipops.lstm_fed_ok(T, B)
                       and hipops.streams_concurrent(grad_overlap.third_side_stream()))
         slab = None
         if stream_own:
@@ -530,7 +530,7 @@ class BLSTMLayerFn(torch.autograd.Function):
             """hh_stream: run the dW_hh product on that stream, beside dW_ih (used where no sweep follows: the tail of
             the step is then two GEMM chains wide instead of one long one)."""
             cur = torch.cuda.current_stream()
-            if hipops.lstm_wgrads_ok(T, B, I):
+            if hipops.lstm_wgrads_ok(T, B, I, npl):
                 # both products in one launch, summed over the time slabs that the streamed order uses: the same bits
                 dwih = torch.empty(G, I, dtype=torch.float32, device=dev)
                 dwhh = torch.empty(2, 4 * HID, HID, dtype=torch.float32, device=dev)

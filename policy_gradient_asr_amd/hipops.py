@@ -337,19 +337,19 @@ def reinforce_grad(scores, path, coef, lengths, out=None, accumulate=False):
 # dense contractions
 # ------------------------------------------------------------------------------------------
 GEMM_XCC_BUSY_PTR = 0   # device address of a sweep's 8 busy counters (0 = plain launch); set around side-stream GEMMs
-GEMM_PRECISION = 1   # default for the model's GEMMs: 1 = bf16x3 split MFMA, 0 = exact fp32 MFMA
-LSTM_PLANES = 2      # bf16 planes per fp32 operand in the recurrent sweeps: 2 = hi/lo, 3 products (default); 3 = hi/mid/lo, 6 products
+GEMM_PRECISION = 0   # the model's GEMMs: 0 = fp32-faithful (six-product / exact fp32 MFMA; the default mode "f32"), 1 = bf16x3 split MFMA
+LSTM_PLANES = 3      # bf16 planes per fp32 operand in the recurrent sweeps: 3 = hi/mid/lo, 6 products (default, "f32"); 2 = hi/lo, 3 products
 
 # The arithmetic of the whole path is a MODE of the host layer:
-#   "bf16x3": every dense product = 3 bf16 MFMA terms of a 2-plane split (~16 operand bits), fp32 accumulate; the input
-#             affine (whose sign feeds leaky_relu') on the exact fp32 MFMA.  Within north_star's 1e-3 bar; the fast path.
-#   "f32":    the reference's arithmetic (torch fp32: nn.Linear / nn.LSTM, model.py:38-44): every fp32 operand of a big product
+#   "bf16x3": (opt-in) every dense product = 3 bf16 MFMA terms of a 2-plane split (~16 operand bits), fp32 accumulate; the input
+#             affine (whose sign feeds leaky_relu') on the exact fp32 MFMA.  Within north_star's 1e-3 bar; ~20 % faster.
+#   "f32":    (the DEFAULT since round 5) the reference's arithmetic (torch fp32: nn.Linear / nn.LSTM, model.py:38-44): every fp32 operand of a big product
 #             as THREE bf16 planes and the product as SIX MFMA terms (every term down to 2^-24) -- the recurrent sweeps
 #             (lstm.hip NP = 3) and, since round 4, the hoisted W_ih products and the weight gradients too (gemm_x6.hip), so the
 #             mode runs the same feed-ahead and streamed orders as "bf16x3"; the small products (input affine, CTC head) on
 #             the exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
 PRECISION_MODES = {"bf16x3": (1, 2), "f32": (0, 3)}
-_precision = "bf16x3"
+_precision = "f32"
 
 
 def set_precision(mode):
@@ -700,10 +700,12 @@ def lstm_wgrad_slabs(T):
     return [int(edges[i]) for i in range(n + 1)]
 
 
-def lstm_wgrads_ok(T, B, in_dim):
-    """Shapes ``lstm_wgrads`` takes (the 256 x 256 TN kernels: both products in one launch) -- in either precision mode:
-    bf16x3 runs gemm_c256.hip's kernel, f32 the six-product one of gemm_x6.hip."""
-    return T >= 2 and in_dim % 256 == 0 and B % 32 == 0 and T * B * 2048 * 4 < 2 ** 31
+def lstm_wgrads_ok(T, B, in_dim, planes=None):
+    """Shapes ``lstm_wgrads`` takes (the 256 x 256 TN kernels: both products in one launch): the time slabs of the sum must be whole
+    k-steps of the kernel -- 16 rows for the six-product kernel of gemm_x6.hip (planes = 3, mode "f32": B % 16 == 0), 32 rows for
+    gemm_c256.hip's bf16x3 kernel (planes = 2: B % 32 == 0).  planes = None: the current precision mode's."""
+    planes = LSTM_PLANES if planes is None else int(planes)
+    return T >= 2 and in_dim % 256 == 0 and B > 0 and B % (16 if planes == 3 else 32) == 0 and T * B * 2048 * 4 < 2 ** 31
 
 
 def lstm_wgrads(dgates, x, out, T, B, in_dim, dwih, dwhh, busy_ptr=0, slab=None, err_ws=None, planes=None):
@@ -929,12 +931,22 @@ def streams_concurrent(other):
     return _concurrent[key]
 
 
-def stream_gate(words_ptr, count=8, timeout_us=60, need=0, running=None):
+GATE_OPENED_ON_BUSY, GATE_OPENED_ON_PUBLICATION, GATE_TIMED_OUT = 1, 2, 3     # report[0] of pgasr_stream_gate_report
+
+
+def stream_gate(words_ptr, count=8, timeout_us=60, need=0, running=None, report=None):
     """Hold the current stream until a sweep has registered in the busy counters at ``words_ptr``; need > 0: until ``need``
     clusters have (consumers that wait for the sweep's publications: all of its workgroups must be resident first) -- or until
-    the first word of ``running`` (the streamed sweep's slab_done words) is non-zero: the sweep is under way or already over."""
+    the first word of ``running`` (the streamed sweep's slab_done words) is non-zero: the sweep is under way or already over.
+    report (need > 0; int32 tensor of >= 2 words): the gate writes how it left (GATE_*) and the microseconds it held the stream."""
     lib = _lib.load()
-    if need > 0:
+    if need > 0 and report is not None:
+        _req(report, torch.int32, "report")
+        if report.numel() < 2:
+            raise _lib.PgasrError("report needs two int32 words")
+        _lib.check(lib.pgasr_stream_gate_report(words_ptr, count, int(need), _p(running), timeout_us, _p(report), _stream()),
+                   "pgasr_stream_gate_report")
+    elif need > 0:
         _lib.check(lib.pgasr_stream_gate_sum(words_ptr, count, int(need), _p(running), timeout_us, _stream()), "pgasr_stream_gate_sum")
     else:
         _lib.check(lib.pgasr_stream_gate(words_ptr, count, timeout_us, _stream()), "pgasr_stream_gate")

@@ -122,9 +122,13 @@ def pg_ctc_loss(logits, in_len, targets, tg_len, lam=1.0, seed=0, offset=0, glob
     log_probs: log_softmax(logits) if the caller already has it (the head kernel's by-product, ``logits.log_probs`` of
     Seq2Seq.logits -- picked up from that attribute when not given)."""
     B = logits.shape[1]
+    if log_probs is None:
+        # the by-product is valid only for the tensor as the head kernel wrote it: any in-place edit since bumps _version
+        log_probs = getattr(logits, "log_probs", None)
+        if log_probs is not None and getattr(logits, "log_probs_version", None) != logits._version:
+            log_probs = None
     return PGCTCLossFn.apply(logits, in_len, targets, tg_len, float(lam), int(seed), int(offset),
-                             int(global_batch or B), int(blank), int(beam), int(sample_base), bool(per_step),
-                             log_probs if log_probs is not None else getattr(logits, "log_probs", None))
+                             int(global_batch or B), int(blank), int(beam), int(sample_base), bool(per_step), log_probs)
 
 
 class CTCLoss(nn.Module):

@@ -6,7 +6,9 @@ Kept names and positional signatures: ``weights``, ``nan_to_num
     keyword makes the F=80 benchmark shape reachable while ``Encoder()`` is unchanged.
   * ``Seq2Seq.forward`` returns (T,B,V) log-probs from a CTC head ``nn.Linear(512, V)`` +
     log_softmax (the reference's Decoder prints a shape and returns None, model.py:117; the
-    consumer contract is model.py:323).  The attention decoder is out of scope.
+    consumer contract is model.py:323).  ``Attention.forward`` / ``Decoder.forward`` (model.py:58-117) run
+    as the reference executes them (pinned by its own outputs); a seq2seq TRAINING mode through them does not exist in
+    the reference and is out of scope.
   * dropout (model.py:45,51 p=0.5; model.py:42 p=0.3) is applied only in train() mode like the
     reference; eval() is the parity mode.
 """
@@ -165,6 +167,7 @@ class Seq2Seq(nn.Module):
             # head + log-softmax in one kernel; the log-probs ride along for the fused loss (pg_ctc_loss takes them from the attribute)
             z, lp = Fh.HeadFn.apply(h, self.head.weight, self.head.bias)
             z.log_probs = lp
+            z.log_probs_version = z._version      # an in-place edit of z afterwards (temperature, masking) invalidates lp: pg_ctc_loss checks
             return z, lengths
         return Fh.LinearFn.apply(h, self.head.weight, self.head.bias), lengths
 
@@ -191,8 +194,26 @@ def _to_device(batch, device):
     return x, t, fmask, tmask
 
 
+FEATURE_DIMS = {"mfcc": 120, "logmel80": 80}      # what data.collate_custom(features=...) produces from a waveform
+
+
+def _check_features(features, n_feats, dataset):
+    """A waveform-carrying dataset meets the model through the front end: its width must be the model's n_feats (a mismatch
+    used to surface as a shape error at the instance norm of the first step)."""
+    if features not in FEATURE_DIMS:
+        raise ValueError(f"features must be one of {sorted(FEATURE_DIMS)}")
+    try:
+        item = dataset[0] if dataset is not None and len(dataset) > 0 else None
+    except Exception:
+        item = None
+    if isinstance(item, dict) and ("wave" in item or "aud" in item) and "feat" not in item:
+        if n_feats != FEATURE_DIMS[features]:
+            raise ValueError(f"features='{features}' gives {FEATURE_DIMS[features]} features per frame but n_feats={n_feats}")
+
+
 def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset=None, dev_dataset=None,
-          n_feats=120, lam=1.0, lr=5e-4, resume=True, log_every=10, seed=0, bucket_by_length=True, features="mfcc"):
+          n_feats=120, lam=1.0, lr=5e-4, resume=True, log_every=10, seed=0, bucket_by_length=True, features="mfcc",
+          precision="f32"):
     """Epoch loop of model.py:186-274 on the MI355X path: per-epoch train loss -> train_loss.npy,
     validation CTC loss -> val_losses.npy, model_best.pth / model_last.pth (state_dicts, reference
     names), plus checkpoint_last.pth (model + Adam moments + epoch) from which ``resume`` restarts
@@ -200,7 +221,9 @@ def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset
     reference's Data(train.tsv / dev.tsv, clips) and accept any Dataset of collate_custom items.
     features: "mfcc" (the reference's 120 MFCC + delta features, n_feats=120) or "logmel80" (80-band log-mel, n_feats=80) for
     items that carry waveforms / audio paths; the collate function leaves the features on the GPU (data.collate_custom(device=...)):
-    from the front end to the trainer they never visit the host."""
+    from the front end to the trainer they never visit the host.
+    precision: "f32" (default: the reference's torch-fp32 arithmetic, model.py:38-44) or "bf16x3" (opt-in, ~20 % faster,
+    within 1e-3 on loss and gradients) -- hipops.PRECISION_MODES."""
     import os
     import numpy as np
     import torch.utils.data as tud
@@ -224,7 +247,8 @@ def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset
     model = Seq2Seq(alphabet_size=len(char2ind), n_feats=n_feats)
     model.apply(weights)                                            # model.py:202
     model = model.to(dev)
-    trainer = PolicyGradientTrainer(model, lr=lr, lam=lam, seed=seed)
+    _check_features(features, n_feats, train_dataset)
+    trainer = PolicyGradientTrainer(model, lr=lr, lam=lam, seed=seed, precision=precision)
     losses, val_losses, best, start_epoch = [], [], 9999999.0, 1
     ckpt = os.path.join(model_path, "checkpoint_last.pth")
     if resume and os.path.exists(ckpt):
@@ -299,14 +323,18 @@ def train(corpus_path, model_path, num_epochs, batch_size, device, train_dataset
 
 
 def predict(test_path, aud_path, alphabet_path, model_path, batch_size, maxlen=None, maxlent=None, device_id=0,
-            test_dataset=None, n_feats=120, beam_size=5):
+            test_dataset=None, n_feats=120, beam_size=5, features="mfcc"):
     """model.py:277-339: load model_best.pth, forward, beam=5 prefix search (device side, batched),
     collapse_fn, CER/WER, predicted.txt.  Frames are cut by the FEATURE mask (the reference cuts the
-    time axis by the target mask, model.py:322 -- a listed defect).  Returns (CER, WER)."""
+    time axis by the target mask, model.py:322 -- a listed defect).  Returns (CER, WER).
+    features: the front end for items that carry waveforms, as in ``train`` ("mfcc": n_feats=120, "logmel80": n_feats=80);
+    the features stay on the device."""
     import os
+    import functools
     import torch.utils.data as tud
     from .CTCdecoder import CTCDecoder, collapse_fn
-    from .data import Data, collate_custom
+    from .data import Data
+    from .data import collate_custom as _collate
     from .metrics import evaluate, save_predictions
 
     alphabet, char2ind = _read_alphabet(alphabet_path)
@@ -317,6 +345,8 @@ def predict(test_path, aud_path, alphabet_path, model_path, batch_size, maxlen=N
     model = model.to(dev).eval()
     if test_dataset is None:
         test_dataset = Data(test_path, aud_path, char2ind)
+    _check_features(features, n_feats, test_dataset)
+    collate_custom = functools.partial(_collate, device=dev, features=features)
     loader = tud.DataLoader(test_dataset, batch_size=batch_size, shuffle=False, collate_fn=collate_custom)
     decoder = CTCDecoder(alphabet)
     targets, predicted, tot_cer, tot_wer, n = [], [], 0.0, 0.0, 0

@@ -73,9 +73,10 @@ class DataParallelStep:
     GLOBAL batch size, so the summed gradient is the global-batch gradient."""
 
     def __init__(self, model, lr=5e-4, world_size=1, process_group=None, precision=None):
-        """precision: "bf16x3" (default: 3-term bf16 split MFMA products, within the 1e-3 bar) or "f32" (the reference's
-        arithmetic, torch fp32: exact fp32 MFMA GEMMs + 3-plane / 6-product recurrent sweeps) -- hipops.PRECISION_MODES;
-        None = whatever mode is set when a step runs."""
+        """precision: "f32" (the library default: the reference's arithmetic, torch fp32 -- every big product as six bf16 MFMA terms
+        of three-plane operands, exact to 2^-24: three-plane sweeps, six-product W_ih projections / input and weight gradients,
+        gemm_x6.hip; the small products on the exact fp32 MFMA) or "bf16x3" (opt-in: 3-term products of two-plane operands, within
+        the 1e-3 bar, ~20 % faster) -- hipops.PRECISION_MODES; None = whatever mode is set when a step runs."""
         if precision is not None:
             from . import hipops
             if precision not in hipops.PRECISION_MODES:
@@ -174,6 +175,16 @@ class DataParallelStep:
         loss.backward()
 
     def step(self, *batch):
+        return self._locked(self._step, batch)
+
+    def compute_gradients(self, *batch):
+        """The step WITHOUT its exchange and update: zero_grad -> forward_loss -> backward in the step's own orders (fed sweeps,
+        streamed weight gradients, side streams), gradients left in ``gflat`` (the parameters' ``.grad`` views), every side stream
+        joined.  Returns the detached local loss.  What the full-size parity tests compare with the oracle; also the hook for a
+        caller that accumulates micro-batches itself."""
+        return self._locked(self._gradients, batch).detach()
+
+    def _locked(self, fn, batch):
         from . import streams
         # every side stream of the step is joined into the calling stream by the time backward() returns, so tensors that
         # cross streams are kept alive until the next step begins instead of being handed to record_stream (streams.hold)
@@ -185,16 +196,20 @@ class DataParallelStep:
                 if self.precision is not None and self.flat.is_cuda:
                     from . import hipops
                     with hipops.precision(self.precision):
-                        return self._step(*batch)
-                return self._step(*batch)
+                        return fn(*batch)
+                return fn(*batch)
         finally:
             _step_lock.release()
 
-    def _step(self, *batch):
+    def _gradients(self, *batch):
         local_b = batch[0].shape[0]
         self.gflat.zero_()
         loss = self.forward_loss(batch, local_b * self.world)
         self.backward(loss)
+        return loss
+
+    def _step(self, *batch):
+        loss = self._gradients(*batch)
         if self.collective:
             # the error flag travels with the last gradient bucket (word 0, see FLAG_PAD): SUM > 0 on every rank iff any
             # rank's gradients are invalid

@@ -49,7 +49,7 @@ def test_python_signature_table_matches_header(lib):
 
 def test_abi_version_and_status_strings(lib):
     lib.pgasr_abi_version.restype = ctypes.c_int
-    assert lib.pgasr_abi_version() == 6
+    assert lib.pgasr_abi_version() == 7
     lib.pgasr_status_string.restype = ctypes.c_char_p
     assert lib.pgasr_status_string(0) == b"ok"
     assert b"workspace" in lib.pgasr_status_string(3)

@@ -104,6 +104,39 @@ def test_encoder_matches_reference(golden_dir):
             assert np.all(y[b, n:] == 0)
 
 
+def test_fast_packed_oracle_equals_packed_sequence_path(golden_dir):
+    """model_ref.encoder_forward_torch(fast_packed=True) -- the packed semantics of model.py:52-55 by reversing every utterance
+    within its own length instead of torch's PackedSequence path (which needs minutes per full-size case on the CPU) -- against (a)
+    the reference's own Encoder outputs (the golden cases, ragged lengths included) and (b) the PackedSequence path in fp64:
+    outputs and every parameter gradient, lengths down to 1."""
+    z = np.load(os.path.join(golden_dir, "encoder_cases.npz"))
+    p = model_ref.init_params(n_feats=120, vocab=29, seed=0)
+    for cid in range(3):
+        x = torch.from_numpy(z[f"x{cid}"]); mask = torch.from_numpy(z[f"mask{cid}"])
+        with torch.no_grad():
+            y = model_ref.encoder_forward_torch(p, x, mask, fast_packed=True).numpy()
+        np.testing.assert_allclose(y, z[f"y{cid}"], rtol=1e-5, atol=1e-6)
+        for b, n in enumerate(mask.sum(1).int().tolist()):
+            assert np.all(y[b, n:] == 0)
+    g = torch.Generator().manual_seed(3)
+    B, F, T = 5, 120, 23
+    lens = [23, 1, 17, 8, 2]
+    x = torch.randn(B, F, T, generator=g, dtype=torch.float64)
+    mask = torch.zeros(B, T)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1; x[b, :, n:] = 0
+    dy = torch.randn(B, T, 512, generator=g, dtype=torch.float64)
+    res = []
+    for fast in (False, True):
+        pr = {k: v.double().requires_grad_(True) for k, v in p.items() if not k.startswith("head.")}
+        y = model_ref.encoder_forward_torch(pr, x, mask, fast_packed=fast)
+        y.backward(dy)
+        res.append((y.detach(), {k: v.grad for k, v in pr.items()}))
+    np.testing.assert_allclose(res[1][0].numpy(), res[0][0].numpy(), rtol=1e-12, atol=1e-13)
+    for k in res[0][1]:
+        np.testing.assert_allclose(res[1][1][k].numpy(), res[0][1][k].numpy(), rtol=1e-9, atol=1e-12, err_msg=k)
+
+
 def test_blstm_numpy_matches_packed_torch(golden_dir):
     z = np.load(os.path.join(golden_dir, "encoder_cases.npz"))
     p = model_ref.init_params(n_feats=120, vocab=29, seed=0)
