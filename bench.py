@@ -698,11 +698,12 @@ def main():
         rl = sweep_roofline(prof, n_sampled, sum(frames) / len(frames), products=prods)
         name, avg_ms, achieved, peak, flops_per_launch = rl["kernel"], rl["avg_launch_ms"], rl["achieved"], rl["peak"], rl["flops_per_launch"]
         traffic, traffic_src = None, None         # HBM bytes per launch of that kernel from the committed PMC passes
-        try:       # written by tools/pmc_summary4.py; the file is optional evidence, never required to run
-            with open(os.path.join(ROOT, "profiles", "r04_pmc.json")) as fi:
+        try:       # written by tools/pmc_summary5.py (round 4: pmc_summary4.py); the file is optional evidence, never required to run
+            pmc_file = next(f for f in ("r05_pmc.json", "r04_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            with open(os.path.join(ROOT, "profiles", pmc_file)) as fi:
                 rec = json.load(fi)[args.precision]["kernels"][name]
             traffic = rec["hbm_bytes_per_launch"]
-            traffic_src = ("from_committed_profile profiles/r04_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
+            traffic_src = ("from_committed_profile profiles/" + pmc_file + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
                            "gfx950 FETCH x2 correction) on the sweep kernels of this precision mode (a counter pass serialises kernels: "
                            "the sequential order of the same kernels); read %.0f MB + write %.0f MB per launch against 262 + 392 MB "
                            "(forward sweep) / 392 + 262 MB (backward sweep) algorithmic"
@@ -715,7 +716,7 @@ def main():
             "metric": METRIC,
             "value": value, "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPES[args.precision], "data": "synthetic",
+            "dtype": DTYPES[args.precision], "precision": args.precision, "data": "synthetic",
             "config": {"workload": ("configs[2]+[1]: CTC + REINFORCE train step (greedy baseline, sampled path, WER-style "
                                     "edit-distance reward), B=32/GPU, T=1000, F=80, V=29, L=100, Adam" if not bucketed else
                                     "configs[4]: CTC + REINFORCE train step with the reference's reward hypothesis (prefix beam "

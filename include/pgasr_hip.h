@@ -117,8 +117,10 @@ int pgasr_head_logsoftmax(const float* x, long long rows, int K, int ldx, const 
  *   sample_path[t,b] ~ softmax(scores[t,b,:]) by inverse CDF with
  *        u = (philox4x32_10(ctr=(t*ctr_stride+ctr_base+b, offset,0,0), key=(seed_lo,seed_hi)).x >> 8) * 2^-24
  *   ctr_stride = 0 means B (counter t*B+b, the single-process layout); a data-parallel rank passes the GLOBAL batch as
- *   ctr_stride and its first utterance's global index as ctr_base (ctr_base + B <= ctr_stride), so that N ranks with one
- *   seed draw what one process holding the whole batch draws.  Either output may be NULL.  V <= 64.
+ *   ctr_stride and its first utterance's global index as ctr_base (0 <= ctr_base < ctr_stride), so that N ranks with one
+ *   seed draw what one process holding the whole batch draws.  Utterances with ctr_base + b >= ctr_stride lie BEYOND the global batch
+ *   (ABI 7: the empty utterances a ragged batch is padded with) and draw from a disjoint domain, ctr = (t*B+b, offset, 1, 0).
+ *   Either output may be NULL.  V <= 64.
  * ---------------------------------------------------------------------------------------- */
 int pgasr_frame_argmax_sample(const float* scores, int T, int B, int V,
                               uint64_t seed, uint32_t offset, int ctr_stride, int ctr_base,

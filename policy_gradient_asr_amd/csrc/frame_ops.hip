@@ -37,8 +37,12 @@ __global__ __launch_bounds__(256) void frame_argmax_sample_kernel(
         uint32_t rnd[4];
         // the draw of frame t of utterance b is addressed by t * ctr_stride + ctr_base + b: with stride = the GLOBAL batch and
         // base = this rank's first utterance, N ranks draw exactly what one process holding the whole batch draws
-        const long long ctr = (r / B) * (long long)ctr_stride + ctr_base + (r % B);
-        philox4x32_10((uint32_t)ctr, offset, 0u, 0u, k0, k1, rnd);
+        // utterances BEYOND the global batch (ctr_base + b >= ctr_stride: the empty utterances a ragged batch is padded with) draw from
+        // a disjoint counter domain (third counter word 1), so their addresses never coincide with a real utterance's
+        const int bg_ = ctr_base + (int)(r % B);
+        const bool outside = bg_ >= ctr_stride;
+        const long long ctr = outside ? (long long)r : (r / B) * (long long)ctr_stride + bg_;
+        philox4x32_10((uint32_t)ctr, offset, outside ? 1u : 0u, 0u, k0, k1, rnd);
         const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
         const float thr = u * total;
         // k = number of labels whose inclusive cdf <= u  (oracle: (cdf <= u).sum())
@@ -216,7 +220,7 @@ extern "C" int pgasr_frame_argmax_sample(const float* scores, int T, int B, int 
                                          int32_t* greedy_path, int32_t* sample_path, void* stream) {
     if (!scores || T <= 0 || B <= 0 || V <= 0) return PGASR_ERR_INVALID_ARG;
     if (ctr_stride == 0) ctr_stride = B;              // the single-process layout: counter = t * B + b
-    if (ctr_stride < B || ctr_base < 0 || ctr_base + B > ctr_stride) return PGASR_ERR_INVALID_ARG;
+    if (ctr_stride <= 0 || ctr_base < 0 || ctr_base >= ctr_stride) return PGASR_ERR_INVALID_ARG;
     if (V > 64) return PGASR_ERR_UNSUPPORTED;
     if (!greedy_path && !sample_path) return PGASR_OK;
     const long long rows = (long long)T * B;

@@ -799,7 +799,14 @@ __global__ __launch_bounds__(256) void pack_x6w_kernel(const float* __restrict__
     blk[1024] = (u32x4_t){l[0], l[1], l[2], l[3]};
 }
 
-constexpr int X6_FEED_SPLIT_MAX = 32;      // split tiles per feed: 4 x 32 slabs of 256 KB = 32 MB of workspace
+constexpr int X6_FEED_SPLIT_MAX = 128;     // split tiles per feed at most: 4 x 128 slabs of 256 KB = 128 MB of workspace (arrival counters: words 64..191 of the head)
+// Time-ordered tile groups (of nt tiles) at the head of a feed whose tiles are split into K-quarters (PGASR_X6_SPLIT_GROUPS, read at every
+// call; the fed and the sequential order read the same value, so they keep giving the same bits).
+int x6_split_groups() {
+    const char* e = getenv("PGASR_X6_SPLIT_GROUPS");
+    const int v = e ? atoi(e) : 16;
+    return v < 0 ? 0 : v;
+}
 // K in quarters for the first tiles of a feed (K >= 1024: the input-gradient feeds).  The K = 512 projections in quarters were measured
 // (round 4, PGASR_X6_QUARTER_K=512, same box, 2 x 40 steps each): forward sweeps 1.54 against 1.47 ms, step 10.67-10.70 against
 // 10.45-10.53 -- four items, a parked accumulator set and a reduction per tile cost the feed more than the first rows gain; the
@@ -842,7 +849,11 @@ extern "C" int pgasr_split_bf16_planes3(const float* src, int rows, int cols, in
 static bool x6w_shape_ok(int M, int N, int K, const float* A, int lda, int ldc, const void* p0, const void* p1, const void* p2) {
     if ((K % x6c::TK) || K < 4 * x6c::TK || (N % x6c::TN) || (lda & 3)) return false;
     if ((((size_t)A) & 15) || (((size_t)p0) & 15) || (((size_t)p1) & 15) || (((size_t)p2) & 15)) return false;
-    if ((size_t)M * ldc * 4 >= ((size_t)1 << 32) || (size_t)M * lda * 4 >= ((size_t)1 << 32)) return false;   // buffer / 32-bit-offset addressing
+    // buffer / 32-bit-offset addressing.  The bound is on the PADDED row count: the epilogue (and the dact_y loads) address the rows of
+    // whole 256-row tiles with 32-bit offsets and rely on the buffer range to drop rows >= M -- an offset that wraps past 2^32 would
+    // land back inside the range and overwrite (read) the first rows instead of being dropped
+    const size_t Mp = ((size_t)M + x6c::TM - 1) / x6c::TM * x6c::TM;
+    if (Mp * ldc * 4 >= ((size_t)1 << 32) || Mp * lda * 4 >= ((size_t)1 << 32)) return false;
     return (M + x6c::TM - 1) / x6c::TM <= 65535;
 }
 
@@ -894,7 +905,7 @@ extern "C" int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int 
     int split = 0;
     if (quarters == 4) {
         const size_t room = (workspace_bytes - 1024) / ((size_t)4 * x6c::SLAB_FLOATS * 4);
-        split = 16 * nt;
+        split = x6_split_groups() * nt;
         if (split > X6_FEED_SPLIT_MAX) split = X6_FEED_SPLIT_MAX;
         if ((size_t)split > room) split = (int)room;
         if (split > mt * nt) split = mt * nt;
@@ -936,11 +947,15 @@ int pgasr_internal_tn6_launch(PgasrTn256Args a, int masked_then_unmasked, hipStr
     if (a.gate && hipFuncSetAttribute((const void*)kgated, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
     const unsigned* busy = a.xcc_busy;
+    // persistent workgroups of the MASKED pass (PGASR_T6_GRID, A/B only; default one per CU = 256, of which those on the sweep's XCDs leave at once)
+    const char* eg = getenv("PGASR_T6_GRID");
+    const int grid0 = (eg && atoi(eg) >= 8 && atoi(eg) <= 256) ? atoi(eg) : 256;
     for (int pass = 0; pass < ((masked_then_unmasked && busy) ? 2 : 1); ++pass) {
         a.xcc_busy = (pass == 0) ? busy : nullptr;
         b.xcc_busy = a.xcc_busy;
-        if (a.gate) PGASR_LAUNCH_KERNEL(kgated, dim3(256), dim3(t6::THREADS), lds, st, a, b);
-        else        PGASR_LAUNCH_KERNEL(kplain, dim3(256), dim3(t6::THREADS), lds, st, a, b);
+        const int grid = (pass == 0 && busy) ? grid0 : 256;
+        if (a.gate) PGASR_LAUNCH_KERNEL(kgated, dim3(grid), dim3(t6::THREADS), lds, st, a, b);
+        else        PGASR_LAUNCH_KERNEL(kplain, dim3(grid), dim3(t6::THREADS), lds, st, a, b);
         PGASR_CHECK_LAUNCH();
     }
     return PGASR_OK;

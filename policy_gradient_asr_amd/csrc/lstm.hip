@@ -111,7 +111,8 @@ struct LstmArgs {
     int T, B, NBG, NCL8;
     int force_mode;          // 0 auto, 1 force write-through (cross-XCD safe), for tests
     int diag;                // diagnostic timing switches (results invalid): bit0 skip bulk stores, bit1 skip xproj prefetch,
-                             // bit2 take the first poll as it comes (no tag check), bit3 no exchange loads at all, bit4 no publish
+                             // bit2 take the first poll as it comes (no tag check), bit3 no exchange loads at all, bit4 no publish,
+                             // bit5 the loader waits for the staging ring but issues no LDS-DMA, bit6 LDS-DMA without waiting for the ring
     long long* stamps;       // diagnostic build only (-DPGASR_LSTM_STAMPS)
 };
 
@@ -133,6 +134,23 @@ struct LstmArgs {
 #define STAMP_DECL
 #define STAMP_FLUSH() do { } while (0)
 #define STAMP(slot) do { } while (0)
+#endif
+
+// Diagnostic build (-DPGASR_LSTM_DIAG): what the loader wave's wait for the staging ring costs.  Per cluster, hello words 48..51 (member 5)
+// and 52..55 (member 0): waits whose first poll found the slot not ready, retries in total, cycles spent in ring_wait, steps.
+#ifdef PGASR_LSTM_DIAG
+#define RW_DECL unsigned rw_late_ = 0, rw_retry_ = 0, rw_steps_ = 0; long long rw_cyc_ = 0, rw_t0_ = 0; bool rw_first_ = true
+#define RW_BEGIN() do { rw_t0_ = clock64(); rw_first_ = true; ++rw_steps_; } while (0)
+#define RW_RETRY() do { if (rw_first_) { ++rw_late_; rw_first_ = false; } ++rw_retry_; } while (0)
+#define RW_END() do { rw_cyc_ += clock64() - rw_t0_; } while (0)
+#define RW_FLUSH() do { if (w == LOADER_WAVE && lane == 0 && (g == 5 || g == 0)) { unsigned* o_ = a.hello + (size_t)cl * HELLO_STRIDE + (g == 5 ? 48 : 52); \
+                        o_[0] = rw_late_; o_[1] = rw_retry_; o_[2] = (unsigned)(rw_cyc_ >> 4); o_[3] = rw_steps_; } } while (0)
+#else
+#define RW_DECL
+#define RW_BEGIN() do { } while (0)
+#define RW_RETRY() do { } while (0)
+#define RW_END() do { } while (0)
+#define RW_FLUSH() do { } while (0)
 #endif
 
 // ---- self-validating exchange words -------------------------------------------------------
@@ -355,7 +373,14 @@ __device__ __forceinline__ void helper_loop(const LstmArgs& a, int cl, int dir, 
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ring, 0, (int)(RING_STEPS * step_floats * 4), 0x00020000);
     unsigned* ready = a.ready + (size_t)cl * 32;
     SpinGuard sg;
+#ifdef PGASR_LSTM_DIAG
+    long long hp_pace_ = 0, hp_fed_ = 0, hp_move_ = 0, hp_t_ = 0; unsigned hp_n_ = 0, hp_lead_ = 0;     // helper 0: cycles waiting for its turn / for the
+                                                                                                         // feed's tiles / moving a step's rows; lead left when done
+#endif
     for (int s = h; s < T; s += N_HELPERS) {
+#ifdef PGASR_LSTM_DIAG
+        hp_t_ = clock64();
+#endif
         // back-pressure: slot s % RING_STEPS held step s - RING_STEPS
         while (true) {
             POLL_FENCE();
@@ -365,6 +390,9 @@ __device__ __forceinline__ void helper_loop(const LstmArgs& a, int cl, int dir, 
             if (!sg.keep_waiting()) { *a.err = 1; return; }
         }
         sg.spins = 0;
+#ifdef PGASR_LSTM_DIAG
+        { const long long n_ = clock64(); hp_pace_ += n_ - hp_t_; hp_t_ = n_; }
+#endif
         const int t = backward ? (dir ? s : T - 1 - s) : (dir ? T - 1 - s : s);
         const unsigned slot_off = (unsigned)((s % RING_STEPS) * step_floats);
         u32x4 v[16];
@@ -386,6 +414,9 @@ __device__ __forceinline__ void helper_loop(const LstmArgs& a, int cl, int dir, 
             sg.spins = 0;
             POLL_FENCE();
         }
+#ifdef PGASR_LSTM_DIAG
+        { const long long n_ = clock64(); hp_fed_ += n_ - hp_t_; hp_t_ = n_; }
+#endif
         if (!backward && a.fed) {
             __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(a.gates, 0, (int)((size_t)T * B * 2 * HID * 4 * 4), 0x00020000);
 #pragma unroll
@@ -459,7 +490,20 @@ __device__ __forceinline__ void helper_loop(const LstmArgs& a, int cl, int dir, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores are complete
         __syncthreads();                                      // .. and so are the other three waves'
         if (tid == 0) __hip_atomic_store(ready + (s % RING_STEPS), (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef PGASR_LSTM_DIAG
+        {
+            const long long n_ = clock64(); hp_move_ += n_ - hp_t_; ++hp_n_;
+            const unsigned cur_ = __hip_atomic_load(a.progress + cl * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hp_lead_ += (unsigned)s > cur_ ? (unsigned)s - cur_ : 0u;      // steps this slot is ahead of member 0 when it becomes ready
+        }
+#endif
     }
+#ifdef PGASR_LSTM_DIAG
+    if (h == 0 && tid == 0) {
+        unsigned* o_ = a.hello + (size_t)cl * HELLO_STRIDE + 56;
+        o_[0] = (unsigned)(hp_pace_ >> 4); o_[1] = (unsigned)(hp_fed_ >> 4); o_[2] = (unsigned)(hp_move_ >> 4); o_[3] = hp_n_; o_[4] = hp_lead_;
+    }
+#endif
     (void)s_flag;
 }
 
@@ -477,6 +521,18 @@ __device__ __forceinline__ void helper_loop(const LstmArgs& a, int cl, int dir, 
 #ifndef PGASR_FWD_XLAYOUT
 #define PGASR_FWD_XLAYOUT 1
 #endif
+// The loader waves' wait for the staging ring (ring_wait) -- what round 5 measured (tools/dev/r5_instep_diag.py, r5_loader_ab.sh, r5_ring_wait.py
+// with the -DPGASR_LSTM_DIAG counters below; f32 train step, one box each):
+//   * with the wait REMOVED (diag bit 6: LDS-DMA from slots that may not be ready) the six sweeps of the step take 1.26-1.32 ms instead of
+//     1.38-1.42 (forward) / 1.31 / 1.60 / 1.61 (backward): the step 8.9 instead of 10.0 ms.  But that is not a per-step cost: the helpers are
+//     late in 2-6 of 1000 steps, and those few waits are ~400 (forward) / ~1,100-1,250 (fed backward) retries long -- the START of a fed
+//     sweep, ~0.1 ms (forward) and ~0.25-0.3 ms (backward) of waiting for the first row tiles of the GEMM that feeds it (backward: that GEMM
+//     gets its CUs only once the previous layer's weight-gradient workgroups have left them).  The backward phase is GEMM-bound (NOTES.md),
+//     so handing the feed those CUs earlier moves work, it does not remove it: more split head tiles (PGASR_X6_SPLIT_GROUPS 16 -> 64) and
+//     fewer persistent weight-gradient workgroups (PGASR_T6_GRID 256 -> 64: fed sweeps 1.61 -> 1.52 ms, tail 0.69 -> 2.9 ms) gained nothing.
+//   * cheaper polls gain little or lose: the first look through the scalar memory path (s_load_dword glc: no vmcnt(0) on the loader's
+//     LDS-DMAs) forward sweeps 1.42 -> 1.385, backward +0.01-0.02, step -0.05 ms; the look taken one iteration early (poll-ahead, LDS-DMAs
+//     right behind the barrier) step +0.1 ms; deeper loader leads (FWD_LEAD 6-8, BWD_LEAD 7-9) backward sweeps +0.03-0.08 ms.  Not kept.
 // The storer waves' result stores (gates / c / h forward, dgates backward) are NON-TEMPORAL: result lines are written once and read
 // by nobody on this XCD, and as ordinary dirty lines they push the helpers' staging ring out of the L2 (whose write-back is the
 // sweeps' excess HBM write traffic).  Round 4, same box, A/B by library: WRITE_SIZE per sweep launch (forward + backward averaged,
@@ -499,7 +555,11 @@ constexpr int LOADER_WAVE = 4, STORER_WAVE = 5;
 #define PGASR_FWD_LEAD 3
 #endif
 constexpr int FWD_LEAD = PGASR_FWD_LEAD, FWD_RING = FWD_LEAD + 2;   // loader runs FWD_LEAD steps ahead; ring slot reuse distance > lead + 1
-constexpr int BWD_LEAD = 4, BWD_RING = 6;
+#ifndef PGASR_BWD_LEAD
+#define PGASR_BWD_LEAD 4
+#endif
+constexpr int BWD_LEAD = PGASR_BWD_LEAD, BWD_RING = BWD_LEAD + 2;
+static_assert(BWD_LEAD >= 3 && 6 * (BWD_LEAD - 2) <= 63 && 4 * FWD_LEAD <= 63, "counted s_waitcnt vmcnt immediates");
 #ifndef PGASR_BWD_POLL_DELAY
 #define PGASR_BWD_POLL_DELAY 2
 #endif
@@ -591,14 +651,18 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
     constexpr int RING_STEPS = FWD_RING_STEPS;
     const float* ring = a.ring + (size_t)cl * RING_STEPS * FWD_STEP_FLOATS;
     const unsigned* ready = a.ready + (size_t)cl * 32;
+    RW_DECL;
     auto ring_wait = [&](int s) {      // until the helpers have staged step s (wave-uniform; only the loader wave waits here)
         SpinGuard sgr;
+        RW_BEGIN();
         while (true) {
             POLL_FENCE();
             if (__hip_atomic_load(ready + (s % RING_STEPS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(s + 1)) break;
+            RW_RETRY();
             if (LDS_FLAG_GET(s_abort) || !sgr.keep_waiting()) { LDS_FLAG_SET(s_abort, 1); *a.err = 1; break; }
             __builtin_amdgcn_s_sleep(1);
         }
+        RW_END();
     };
     auto loader_issue = [&](int s) {
         if (a.diag & 2) return;
@@ -613,7 +677,8 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
             }
             return;
         }
-        ring_wait(sc);
+        if (!(a.diag & 64)) ring_wait(sc);
+        if (a.diag & 32) return;
         const float* slot = ring + (size_t)(sc % RING_STEPS) * FWD_STEP_FLOATS;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -810,6 +875,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
     STAMP_FLUSH();
     __syncthreads();
     if (w == STORER_WAVE && !LDS_FLAG_GET(s_abort) && T > 0) io_store_results(T - 1);
+    RW_FLUSH();
     release_xcd(a, g, tid);
 }
 
@@ -880,14 +946,18 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
     constexpr int RING_STEPS = BWD_RING_STEPS;
     const float* ring = a.ring + (size_t)cl * RING_STEPS * BWD_STEP_FLOATS;
     const unsigned* ready = a.ready + (size_t)cl * 32;
+    RW_DECL;
     auto ring_wait = [&](int s) {      // until the helpers have staged step s (wave-uniform; only the loader wave waits here)
         SpinGuard sgr;
+        RW_BEGIN();
         while (true) {
             POLL_FENCE();
             if (__hip_atomic_load(ready + (s % RING_STEPS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(s + 1)) break;
+            RW_RETRY();
             if (LDS_FLAG_GET(s_abort) || !sgr.keep_waiting()) { LDS_FLAG_SET(s_abort, 1); *a.err = 1; break; }
             __builtin_amdgcn_s_sleep(1);
         }
+        RW_END();
     };
     auto loader_issue = [&](int s) {
         if (a.diag & 2) return;
@@ -907,7 +977,8 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
             dma16(a.dout + ((size_t)t * B + b) * (2 * HID) + dir * HID + u0, &sdy[slot][0]);
             return;
         }
-        ring_wait(sc);
+        if (!(a.diag & 64)) ring_wait(sc);
+        if (a.diag & 32) return;
         const float* rs_ = ring + (size_t)(sc % RING_STEPS) * BWD_STEP_FLOATS;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -941,7 +1012,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
             // cells of step+1 read rows(step+1) and c_t(step+2) before the NEXT barrier: keep only the two
             // youngest steps (12 instructions) in flight
             loader_issue(step + BWD_LEAD);
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * (BWD_LEAD - 2)) : "memory");
             LDS_BARRIER();
             if (LDS_FLAG_GET(s_abort)) break;
         }
@@ -1133,6 +1204,7 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
             *reinterpret_cast<float4*>(a.dbias_part + (((size_t)bg * 2 + dir) * HID + 16 * g + tid) * 4) = sum;
         }
     }
+    RW_FLUSH();
     release_xcd(a, g, tid);
 }
 

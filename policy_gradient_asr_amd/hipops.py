@@ -456,7 +456,8 @@ def gemm_x3w_ok(M, N, K, lda=None, planes=2):
     """Shapes the LDS-DMA kernels take (else use ``gemm``): planes = 2 the bf16x3 kernels, 3 the six-product ones."""
     lda = K if lda is None else lda
     if planes == 3:
-        return K % 16 == 0 and K >= 64 and N % 256 == 0 and lda % 4 == 0 and M > 0 and M * max(N, lda) * 4 < 2 ** 32
+        Mp = (M + 255) // 256 * 256       # the kernel addresses whole 256-row tiles with 32-bit offsets (x6w_shape_ok, gemm_x6.hip)
+        return K % 16 == 0 and K >= 64 and N % 256 == 0 and lda % 4 == 0 and M > 0 and Mp * max(N, lda) * 4 < 2 ** 32
     return K % 32 == 0 and N % 128 == 0 and lda % 4 == 0 and M > 0
 
 

@@ -272,6 +272,12 @@ class PolicyGradientTrainer(DataParallelStep):
         self._one = None
         self.last_stats = None
         self.overlap_weight_grads = True
+        # A batch whose size the fast orders do not take (feed-ahead: B <= 32; streamed weight gradients: B % 16 == 0 in "f32", B % 32
+        # == 0 in "bf16x3") is padded with EMPTY utterances (no frames, no target) up to the next such size: the last, ragged batch of an
+        # epoch (model.py:221-222 leaves it as it comes) then runs the same orders as every other batch.  An empty utterance adds nothing
+        # to the loss or to any gradient (CTC of nothing against nothing is 0, its rewards are 0, the sweeps skip it), the loss keeps
+        # its normalisation by the REAL batch, the sampler its addressing; a 16-utterance group costs a sweep the same full or not.
+        self.pad_ragged_batches = True
         # N > 1: the gradients of the head and of BLSTM layers 1, 2 (2/3 of the bytes) are all-reduced under the tail
         # of backward (the first layer's three GEMMs and the affine gradients), the rest after it
         self.early_reduce = os.environ.get("PGASR_EARLY_REDUCE", "1") != "0"
@@ -346,11 +352,26 @@ class PolicyGradientTrainer(DataParallelStep):
             grad_overlap.upper_grads_hook = None
             grad_overlap.finish()
 
+    def _padded(self, x, targets, fmask, tmask):
+        """The batch with empty utterances appended up to the next size the fast orders take (see ``pad_ragged_batches``)."""
+        from . import hipops
+        B = x.shape[0]
+        q = 16 if hipops.LSTM_PLANES == 3 else 32
+        Bp = -(-B // q) * q
+        if not (self.pad_ragged_batches and x.is_cuda and Bp != B and Bp <= 32 and targets.dim() == 2 and fmask.dim() == 2):
+            return x, targets, fmask, tmask
+        n = Bp - B
+        grow = lambda t_: torch.cat((t_, t_.new_zeros((n,) + tuple(t_.shape[1:]))), dim=0)
+        return grow(x), grow(targets), grow(fmask), grow(tmask)
+
     def forward_loss(self, batch, global_batch):
         from .loss import pg_ctc_loss
         x, targets, fmask, tmask = batch
         from . import hipops
         self._check_limits(x, targets)
+        real_b = x.shape[0]
+        x, targets, fmask, tmask = self._padded(x, targets, fmask, tmask)
+        padded = x.shape[0] != real_b
         if (fmask.dtype == torch.float32 and tmask.dtype == torch.int64 and targets.dtype == torch.int64 and targets.dim() == 2
                 and targets.shape[1] > 0 and fmask.is_contiguous() and tmask.is_contiguous() and targets.is_contiguous()):
             in_len, tg_len, tg = hipops.batch_prep(fmask, tmask, targets)       # the collate_custom dtypes: one launch
@@ -362,7 +383,7 @@ class PolicyGradientTrainer(DataParallelStep):
         loss, nll, R_s, R_g = pg_ctc_loss(logits, in_len, tg, tg_len, lam=self.lam, seed=self.seed,
                                           offset=self.nstep + 1, global_batch=global_batch, blank=self.blank,
                                           beam=self.beam_size if self.reward_decoder == "beam" else 0,
-                                          sample_base=self.rank * x.shape[0] if self.world > 1 else -1,
+                                          sample_base=self.rank * real_b if (self.world > 1 or padded) else -1,
                                           per_step=self.reward_mode == "per_step")
-        self.last_stats = (nll, R_s, R_g)
+        self.last_stats = (nll[:real_b], R_s[:real_b], R_g[:real_b]) if padded else (nll, R_s, R_g)
         return loss

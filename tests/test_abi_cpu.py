@@ -104,3 +104,16 @@ def test_product_package_never_imports_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_host_side_shape_rules():
+    """Pure-Python shape predicates of the host layer (no GPU call): the six-product kernels address whole 256-row tiles with 32-bit
+    offsets, so the 4 GiB bound is on the PADDED row count; streamed weight gradients take B % 16 in the six-product
+    arithmetic and B % 32 in bf16x3; the library's default precision mode is the reference's arithmetic."""
+    from policy_gradient_asr_amd import hipops
+    assert hipops.get_precision() == "f32" and hipops.PRECISION_MODES[hipops.get_precision()] == (hipops.GEMM_PRECISION, hipops.LSTM_PLANES)
+    assert hipops.gemm_x3w_ok(2047 * 256, 2048, 512, planes=3)                  # 2047 tiles x 2048 x 4 B < 4 GiB
+    assert not hipops.gemm_x3w_ok(2047 * 256 + 1, 2048, 512, planes=3)          # M itself is below the bound, its last tile's rows are not
+    assert not hipops.gemm_x3w_ok(524287, 2048, 512, planes=3) and hipops.gemm_x3w_ok(524287, 256, 512, planes=3)
+    assert hipops.lstm_wgrads_ok(200, 16, 512, 3) and not hipops.lstm_wgrads_ok(200, 16, 512, 2)
+    assert hipops.lstm_wgrads_ok(200, 32, 512, 2) and not hipops.lstm_wgrads_ok(200, 24, 512, 3) and not hipops.lstm_wgrads_ok(1, 32, 512, 3)

@@ -293,6 +293,12 @@ def test_sampler_draws_are_addressed_globally_across_shards():
         assert torch.equal(part, whole[:, base:base + nb])
     _, local = ops.frame_argmax_sample(scores[:, 4:8].contiguous(), seed=99, offset=7, want_greedy=False)
     assert not torch.equal(local, whole[:, 4:8])          # without the layout a shard draws its own (local) counters
+    # utterances beyond the global batch (a ragged batch padded with empty utterances, round 5): the real ones keep their draws, the
+    # padding draws from a disjoint domain
+    padded = torch.cat((scores[:, :5], scores[:, :3]), dim=1).contiguous()
+    _, part = ops.frame_argmax_sample(padded, seed=99, offset=7, want_greedy=False, batch_stride=5, batch_offset=0)
+    _, five = ops.frame_argmax_sample(scores[:, :5].contiguous(), seed=99, offset=7, want_greedy=False)
+    assert torch.equal(part[:, :5], five) and not torch.equal(part[:, 5:], five[:, :3])
     import pytest
     with pytest.raises(Exception):
-        ops.frame_argmax_sample(scores[:, :4].contiguous(), seed=1, want_greedy=False, batch_stride=6, batch_offset=4)   # base + B > stride
+        ops.frame_argmax_sample(scores[:, :4].contiguous(), seed=1, want_greedy=False, batch_stride=6, batch_offset=6)   # base outside the batch

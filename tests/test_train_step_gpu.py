@@ -497,6 +497,36 @@ def test_trainer_steps_reduce_loss():
     assert m.head.weight.data_ptr() >= tr.flat.data_ptr()
 
 
+@pytest.mark.parametrize("B,reward", [(7, "greedy"), (21, "greedy"), (5, "beam")])
+def test_ragged_batch_is_padded_with_empty_utterances(B, reward):
+    """PolicyGradientTrainer.pad_ragged_batches (round 5): a batch size the fast orders do not take (the last batch of an epoch,
+    model.py:221-222) is filled up with EMPTY utterances to the next multiple of 16 and runs the fed + streamed orders.  The step must be
+    the step of the un-padded batch: same sampled paths and rewards (exactly), same loss, same gradients to fp32 rounding (lambda = 1,
+    eval mode so that no dropout mask depends on the batch shape), statistics of the REAL utterances only."""
+    from policy_gradient_asr_amd import hipops
+    from policy_gradient_asr_amd.model import Seq2Seq, weights
+    from policy_gradient_asr_amd.train_step import PolicyGradientTrainer
+    F, T, V, L = 80, 60, 29, 6
+    lens = [T - (3 * b) % 17 for b in range(B)]
+    x, targets, fmask, tmask = _make(B, F, T, V, L, lens, [max(1, L - b % 4) for b in range(B)], 8)
+    batch = [v.to(DEV) for v in (x, targets, fmask, tmask)]
+    res = {}
+    for pad in (False, True):
+        torch.manual_seed(0)
+        m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(DEV).eval()
+        tr = PolicyGradientTrainer(m, lam=1.0, seed=4, precision="f32", reward_decoder=reward, beam_size=16)
+        tr.pad_ragged_batches = pad
+        loss = tr.compute_gradients(*batch)
+        torch.cuda.synchronize()
+        hipops.lstm_assert_no_timeouts()
+        res[pad] = (float(loss), tr.gflat.clone(), [s_.clone() for s_ in tr.last_stats])
+    assert all(s_.shape == (B,) for s_ in res[True][2])
+    assert torch.equal(res[True][2][1], res[False][2][1]) and torch.equal(res[True][2][2], res[False][2][2])     # R_s, R_g
+    assert rel_err(res[True][2][0].cpu(), res[False][2][0].cpu()) < 1e-6                                            # nll
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
+    assert rel_err(res[True][1].cpu(), res[False][1].cpu()) < 1e-5 and float(res[False][1].abs().max()) > 0
+
+
 def test_dropout_kernel_mask_and_backward():
     from policy_gradient_asr_amd import hipops, functional as Fh
     x = torch.ones(1000, 37, device=DEV)     # odd size exercises the tail
