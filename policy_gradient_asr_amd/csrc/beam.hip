@@ -308,6 +308,9 @@ inline size_t beam_lds_bytes(int K, int V) {
 //     on the low words) pop the winners in rank order (a pop shifts the winner lane's register list).
 //   frames are staged 32 at a time through LDS, two chunks ahead in registers, so no load is ever waited for.
 // =====================================================================================================================
+#ifdef PGASR_BEAM_DIAG
+__device__ unsigned long long beam_diag_counters[4];      // frames, frames redone by the exact rounds, -, -
+#endif
 namespace sb {
 constexpr int K_MAX = 16, V_MAX = 32, H = 32768, CH = 32;
 constexpr long long MAX_NODES = 24576;               // T * beam: load factor of the table <= 0.75
@@ -519,6 +522,9 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
                 const unsigned slot = (wperm >> (3 * idx)) & 7u;
                 packed = ((wl >> 4) << 7) | (slot << 4) | (wl & 15u);
             } else {
+#ifdef PGASR_BEAM_DIAG
+                if (lane == 0) atomicAdd(&beam_diag_counters[1], 1ull);
+#endif
                 // exact rounds on the full keys (ties between high words; rare)
                 for (int r = 0; r < K; ++r) {
                     const unsigned long long head = k[0];
@@ -545,6 +551,9 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
             }
         }
 
+#ifdef PGASR_BEAM_DIAG
+        if (lane == 0) atomicAdd(&beam_diag_counters[0], 1ull);
+#endif
         // ---- the new beam: entry r <- winner r ----
         const int pj = (int)(packed & 15u), slot = (int)((packed >> 4) & 7u), pq = (int)(packed >> 7);
         const int s = 8 * pq + slot;
@@ -630,6 +639,14 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
 }  // namespace sb
 
 }  // namespace
+
+#ifdef PGASR_BEAM_DIAG
+extern "C" int pgasr_diag_beam_counters(unsigned long long* out, int reset) {      // host copy of (frames, frames redone by the exact rounds)
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(beam_diag_counters), sizeof(unsigned long long) * 4) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(beam_diag_counters), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 extern "C" size_t pgasr_beam_workspace_bytes(int T, int B, int V, int beam) {
     if (T <= 0 || B <= 0 || V <= 0 || beam <= 0) return 0;

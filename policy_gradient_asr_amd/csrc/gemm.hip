@@ -829,6 +829,13 @@ extern "C" int pgasr_lstm_wgrads_streamed(const float* dgates, const float* x, c
     if (hipMemsetAsync(workspace, 0, 256, st) != hipSuccess) return PGASR_ERR_LAUNCH;
     const int rc = planes == 3 ? pgasr_internal_tn6_launch(ih, 1, st, &hh) : pgasr_internal_tn256_launch(ih, 1, st, &hh);
     if (rc != PGASR_OK) return rc;
+    // Why the time-slab partials are summed by two small launches and not by the last-arriving workgroup of each tile (asked twice in
+    // review): (1) the sum over the slabs IN SLAB ORDER is what makes every order of a step give the same bits, and a fixed-order sum by
+    // "whoever arrives last" means that workgroup reads 11 partial tiles of 256 KB one after the other on ONE CU (~2.9 MB at the ~0.15 TB/s
+    // a single CU streams: ~20 us per tile, 24 tiles) while it holds a persistent slot of the queue the still-running sweep feeds; the two
+    // launches move the same 34 MB with the whole chip in 46-54 + 13-16 us (kernel timeline of a step, profiles/r04_step_timeline_f32.txt).
+    // (2) They are not on the step's chain: they run on the weight-gradient stream behind the products, beside the NEXT layer's sweep; the
+    // first layer's (the tail) run beside the main stream's dropout -> input-layer gradient -> Adam chain and end before it does.
     PGASR_LAUNCH_KERNEL(gemm_reduce_kernel, dim3((unsigned)(((size_t)G * in_dim + 255) / 256), 1), dim3(256), 0, st,
                        part_ih, nslab, G, in_dim, dwih_perm, in_dim, (long long)0, (const float*)nullptr, (const float*)nullptr, 0, 0.f, 0);
     PGASR_CHECK_LAUNCH();

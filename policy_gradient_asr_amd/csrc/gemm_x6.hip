@@ -120,6 +120,13 @@ __device__ __forceinline__ void mfma6(f32x16 (&acc)[2], const u32x4_t (&a)[3], c
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[PA[p]]), __builtin_bit_cast(bf16x8_t, b[j][PB[p]]), acc[j], 0, 0, 0);
 }
 
+// Round 5 note -- why the A operand is still converted in the k-loop.  The review asked for activations delivered as three bf16 planes by
+// their producers (the sweeps' storer waves, the affine / dropout epilogues), so that both operands become LDS-DMA operands.  The upper
+// bounds were already measured with this kernel's diagnostic build (round 4, NOTES.md 1.3, 1.5): the input-gradient shape runs 410 us, 384
+// WITHOUT any conversion (-6 %), and the weight-gradient kernel 373 -> 374 -> 376 us with its B operand left unsplit, unstored and then
+// unloaded (0 %): what these kernels pay for is MFMA issue (1.7-1.9 PF is what the chip sustains on bare MFMAs), fragment reads and the step
+// barrier.  Against at most -6 % on one of the two kernels stand +50 % bytes written by every sweep (393 instead of 262 MB per layer, by
+// sweeps that slow down 24 % beside 2.9 TB/s of foreign traffic) and a second 393 MB buffer per layer.  Not built.
 // VAR (PGASR_X6_VAR, read at every call; bit-identical results): 7 (default) = SELF-INTERLEAVED, every wave carries its own non-MFMA
 // work as fillers behind its own MFMAs; 0 = gemm_c256.hip's structure (two row tiles' fragments read, waited for, multiplied; the
 // conversion as a block, the two waves of a SIMD half a step out of phase).  Round 4 measured five more structures on one box --

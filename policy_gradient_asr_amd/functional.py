@@ -150,6 +150,12 @@ class grad_overlap:
             torch.cuda.current_stream().wait_stream(cls.second_side_stream())
 
 
+# The input layer's weight gradient is B batches of a (512 x F x T) product: at B = 32 that is 128 work items of 128 x 128 on 256 CUs, each
+# a thousand frames deep, and it is the last dependent GEMM of the step's tail.  Split-K 2 fills the chip: 166 -> 99 us at the headline shape
+# (4: 98, 8: 133; tools/dev/r5_affine_dw.py, round 5).  One value for every order of the step, so they keep giving the same bits.
+AFFINE_DW_SPLITK = 2       # for T >= 256 frames
+
+
 class InstNormAffineFn(torch.autograd.Function):
     """model.py:48-50: InstanceNorm2d over the (F,T) plane -> Linear(F,512) -> leaky_relu.
     x (B,F,T) -> y (T,B,N).  The normalisation is applied while the GEMM loads its tile."""
@@ -204,7 +210,7 @@ class InstNormAffineFn(torch.autograd.Function):
             # .. and the weight gradient is summed into weight.grad by the GEMM's own slab reduction (one launch less on the chain)
             hipops.gemm(dpre, x, dW, M=N, N=F, K=T, transA=True, transB=True, lda=B * N, ldb=T, ldc=F,
                         strideA=N, strideB=F * T, strideC=0, batch=B, sum_batches=True, norm_operand=2,
-                        shift=mean, scale=rstd, accumulate=direct)
+                        shift=mean, scale=rstd, accumulate=direct, splitk=AFFINE_DW_SPLITK if T >= 256 else 1)
             return (None, None if direct else dW, None, None)
         return (None, *InstNormAffineFn.param_grads(x, mean, rstd, dpre, N), None)
 
@@ -214,7 +220,7 @@ class InstNormAffineFn(torch.autograd.Function):
         dW = torch.empty(N, F, dtype=torch.float32, device=x.device)
         hipops.gemm(dpre, x, dW, M=N, N=F, K=T, transA=True, transB=True, lda=B * N, ldb=T, ldc=F,
                     strideA=N, strideB=F * T, strideC=0, batch=B, sum_batches=True, norm_operand=2,
-                    shift=mean, scale=rstd)
+                    shift=mean, scale=rstd, splitk=AFFINE_DW_SPLITK if T >= 256 else 1)
         db = torch.empty(N, dtype=torch.float32, device=x.device)
         hipops.colsum(dpre, T * B, N, N, db)
         return dW, db

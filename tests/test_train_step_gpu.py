@@ -794,13 +794,13 @@ def test_train_mode_step_runs_with_dropout():
 def test_headline_size_loss_and_gradient_parity(mode):
     """north_star criterion at the benchmark shape itself (B=32,T=1000,F=80,V=29,L=100), in both precision modes, against the
     torch-CPU model in FP64 on the same weights: CTC loss and parameter gradients (max-norm relative) within 1e-3 for
-    bf16x3, within 1e-5 / 1e-4 for f32 (the benchmarked mode: the reference's torch fp32 arithmetic, model.py:38-44, run as
+    bf16x3, within 1e-5 / 5e-5 for f32 (the benchmarked mode: the reference's torch fp32 arithmetic, model.py:38-44, run as
     fed + streamed three-plane sweeps and six-product GEMMs); greedy-decoded token indices bit-exact on the oracle's logits."""
     from policy_gradient_asr_amd.model import Seq2Seq
     from policy_gradient_asr_amd.train_step import PolicyGradientTrainer
     from policy_gradient_asr_amd import hipops
     B, F, T, V, L = 32, 80, 1000, 29, 100
-    tol_loss, tol_grad = (1e-5, 1e-4) if mode == "f32" else (1e-3, 1e-3)
+    tol_loss, tol_grad = (1e-5, 5e-5) if mode == "f32" else (1e-3, 1e-3)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, F, T, generator=g)
     targets = torch.randint(1, V, (B, L), generator=g)
@@ -808,15 +808,26 @@ def test_headline_size_loss_and_gradient_parity(mode):
     p = model_ref.init_params(n_feats=F, vocab=V, seed=0)
     pr = {k: v.double().requires_grad_(True) for k, v in p.items()}
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    enc = model_ref.encoder_forward_torch(pr, x.double(), fmask, packed=False)     # lengths == T: same arithmetic as packed
+    m = Seq2Seq(V, n_feats=F)
+    m.load_state_dict({("encoder." + k if not k.startswith("head.") else k): v for k, v in p.items()}, strict=True)
+    m = m.to(DEV).eval()
+    # the one discrete choice of a CTC-only step: which side of leaky_relu (model.py:50) a pre-activation of the input layer falls on.  Two
+    # evaluations that agree to 1e-7 still disagree on a handful of 16 M pre-activations that are zero to rounding, and each one scales a
+    # summand of the input layer's gradient by 100 (measured: 9.5e-5 max norm from ONE flipped side, in either precision mode -- the affine
+    # is exact fp32 in both): the oracle takes the device's sides after the count of differences has been asserted (as _pg_step_vs_oracle)
+    from policy_gradient_asr_amd import functional as Fh
+    with torch.no_grad():
+        side = (Fh.InstNormAffineFn.apply(x.to(DEV), m.encoder.input_layer.weight, m.encoder.input_layer.bias) > 0).permute(1, 0, 2).cpu()
+        own = torch.nn.functional.linear(model_ref.instance_norm(x).transpose(1, 2), p["input_layer.weight"], p["input_layer.bias"]) > 0
+        n_flip = int((side != own).sum())
+    print(f"[parity] leaky_relu sides that differ between device and torch-CPU fp32: {n_flip} of {side.numel()}")
+    assert n_flip <= 32, n_flip
+    enc = model_ref.encoder_forward_torch(pr, x.double(), fmask, packed=False, leaky_side=side)     # lengths == T: same arithmetic as packed
     logits_ref = model_ref.head_logits_torch(pr, enc)
     lp_ref = torch.log_softmax(logits_ref, 2)
     il = torch.full((B,), T, dtype=torch.long); tl = torch.full((B,), L, dtype=torch.long)
     ref = torch.nn.functional.ctc_loss(lp_ref, targets, il, tl, blank=0, reduction="mean")
     ref.backward()
-    m = Seq2Seq(V, n_feats=F)
-    m.load_state_dict({("encoder." + k if not k.startswith("head.") else k): v for k, v in p.items()}, strict=True)
-    m = m.to(DEV).eval()
     # through the TRAINER: the orders the benchmark runs (fed sweeps, streamed weight gradients, side streams)
     tr = PolicyGradientTrainer(m, lam=0.0, precision=mode)
     loss = tr.compute_gradients(x.to(DEV), targets.to(DEV), fmask.to(DEV), torch.ones(B, L, dtype=torch.int64, device=DEV))
