@@ -18,6 +18,17 @@
 // instructions of one wave per SIMD.  The frame is bound by the dependent-issue latency of a single wave's instruction
 // chain, not by the barrier, the LDS round trip, the emission loads or the stores; more waves do not shorten a chain.
 //
+// Measured and NOT kept (round 5, commit cdcbccd): a LINEAR-domain lattice for S <= 256 -- one compute wave per utterance and direction,
+// four adjacent states per lane, alpha_t(s) = p_t(s) (alpha_{t-1}(s) + alpha_{t-1}(s-1) + [skip] alpha_{t-1}(s-2)) as two additions and a
+// multiplication per state instead of an lse3, neighbours by DPP wave_shr / wave_shl, block floating point with one binary exponent per
+// lane (re-based on the neighbour's when that is far above), a feeder wave turning log-probs into probabilities 32 frames at a time, three
+// storer waves writing the same workspace format, a redo in log space when fp32's range empties the lattice.  Bit-for-bit the same nll to
+// eight digits and all CTC tests green -- and 0.31 us per frame in fp64 (fp64 vector instructions issue at half rate), 0.31 in fp32 with
+// per-frame renormalisation, 0.36 with exponents frozen for four frames, against 0.27 for the kernel below.  In-kernel clocks: 709 cycles per
+// frame at 2.4 GHz for ~45 vector instructions, 490 with every LDS access removed: once more (see the round-3 note above) a frame of ONE
+// wave costs the dependent-issue latency of its chain, ~13-20 cycles per dependent instruction, plus an LDS round trip -- shortening the
+// arithmetic does not shorten that.  The lattice stays at 0.27 us per frame.
+//
 // Numerics: alpha/beta are kept in fp64 (adds/max are native fp64 VALU ops) while exp/log
 // run in fp32 on the *differences* to the row maximum, which are O(1..50): absolute error
 // per step ~1e-7 instead of the ~2e-4 ulp an fp32 log-space value of magnitude 3000 has at
@@ -302,308 +313,6 @@ __global__ __launch_bounds__(CTC_THREADS + 64) void ctc_lattice_kernel(
 }
 
 
-// =====================================================================================================================
-// Linear-domain lattice for S <= 256 (round 5): ONE compute wave per utterance and direction walks the T frames, four
-// adjacent states per lane, in SCALED PROBABILITIES instead of log space:
-//     alpha_t(s) = p_t(s) * (alpha_{t-1}(s) + alpha_{t-1}(s-1) + [skip] alpha_{t-1}(s-2))        (beta: mirrored)
-// is two additions and one multiplication per state and frame -- against max, three differences, three exp2, a log2 and
-// their conversions for a log-space lse3.  Rounds 1-3 found the log-space frame bound by the dependent-issue latency of one
-// wave's ~60-instruction chain (0.27 us per frame whatever the barrier, the LDS round trip or the stores cost, see the
-// header); the chain of a frame here is neighbour hand-off (DPP wave_shr / wave_shl) -> rescale -> add -> fma -> mul.
-// Arithmetic: fp32 values with a binary exponent PER LANE (true value = a * 2^e: block floating point over the lane's four
-// adjacent states), renormalised every frame (v_frexp_exp / v_ldexp); the neighbour's exponent travels with its values, and
-// a lane whose neighbour is more than 2^32 above it re-bases itself on the neighbour's exponent (what it held is below the
-// resolution of what flows in).  So states far from the mass keep their true magnitude across the row -- a whole-row scale
-// factor (the textbook scaled forward pass) would flush states 87 nats below the row maximum, which is where the path of a
-// badly fitting transcript lies.  (The first version of this kernel kept fp64 values: fp64 vector instructions issue at half
-// rate and v_ldexp_f64 slower still -- 0.31 us per frame, slower than the log-space kernel it was to replace.)  Rounding:
-// ~1e-7 relative per frame, a random walk of ~5e-6 over 1000 frames in alpha -- the log-space kernel's fp32 exp2 / log2 on
-// differences are of the same order.  What fp32 cannot hold is a frame probability below 2^-126 (log-prob < -87): it becomes
-// 0.  If that empties the whole lattice (likelihood 0 although the alignment is feasible) the workgroup REDOES its direction
-// with the log-space body below; short of that, a path through such a frame weighs e^-87 of the total and is dropped.
-// Other waves of the workgroup, none on the chain: a FEEDER turns log-probs into probabilities 32 frames at a time (exp2 of
-// the fractional part, the integer part by ldexp), three STORERS turn finished rows into the fp32 log offsets + fp64 row
-// reference the gradient pass reads (the same workspace format as the log-space kernel: ctc_grad_kernel does not know which
-// lattice kernel ran).  Hand-offs through LDS rings with monotonic counters; every wait is bounded (-> redo in log space).
-// =====================================================================================================================
-typedef __attribute__((ext_vector_type(4))) float pgasr_f4;
-namespace lin {
-constexpr int RING = 32;              // finished rows between the compute wave and the storers
-constexpr int NSTORE = 3;
-constexpr int CH = 32;                // frames per emission chunk
-constexpr int WAVES = 2 + NSTORE;     // compute, feeder, storers
-constexpr int THREADS = 64 * WAVES;
-constexpr int SPIN_MAX = 1 << 22;
-constexpr int REBASE = 16;            // a neighbour more than 2^REBASE above this lane: take its exponent
-struct Lds {
-    float ring_a[RING][64][4];        // 32 KB
-    int ring_e[RING][64];             //  8 KB
-    float pbuf[2][CH][64];            // 16 KB: probabilities of the frame's symbols, two chunks
-    int done, st[NSTORE], fed, cchunk, bad, redo;
-};
-template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-#define LIN_GET(var) __hip_atomic_load(&(var), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define LIN_SET(var, val) __hip_atomic_store(&(var), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-// wave-uniform bounded wait for  counter >= want
-__device__ __forceinline__ bool wait_ge(int& counter, int want, int& bad) {
-    for (int spin = 0; ; ++spin) {
-        asm volatile("" ::: "memory");
-        if (LIN_GET(counter) >= want) return true;
-        if (LIN_GET(bad) || spin > SPIN_MAX) { LIN_SET(bad, 1); return false; }
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-}  // namespace lin
-
-// returns (to every thread of the workgroup) whether the direction has to be redone in log space
-template <int ROLE>
-__device__ __forceinline__ bool ctc_lattice_lin_body(
-    const float* __restrict__ lp, const int32_t* __restrict__ targets, const int32_t* __restrict__ in_len,
-    const int32_t* __restrict__ tg_len, int T, int B, int V, int Lmax, int blank, CtcWs ws, float* __restrict__ nll_out, lin::Lds& L, int diag) {
-    using namespace lin;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    int Tb = in_len[b]; Tb = Tb < 0 ? 0 : (Tb > T ? T : Tb);
-    int Lb = tg_len[b]; Lb = Lb < 0 ? 0 : (Lb > Lmax ? Lmax : Lb);
-    const int S = 2 * Lb + 1;
-    const int32_t* tgt = targets + (size_t)b * Lmax;
-    if (tid == 0) {
-        LIN_SET(L.done, 0); LIN_SET(L.fed, 0); LIN_SET(L.cchunk, 0); LIN_SET(L.bad, 0); LIN_SET(L.redo, 0);
-        for (int i = 0; i < NSTORE; ++i) LIN_SET(L.st[i], 0);
-    }
-    __syncthreads();
-    if (Tb == 0) {
-        if (ROLE == 0 && tid == 0) { const double v = (Lb == 0) ? 0.0 : INFINITY; ws.nll64[b] = v; nll_out[b] = (float)v; }
-        return false;
-    }
-    const int t0 = (ROLE == 0) ? 0 : Tb - 1, dt = (ROLE == 0) ? 1 : -1;
-    const int nchunk = (Tb + CH - 1) / CH;
-
-    if (w == 1) {
-        // ---- feeder: chunk c = sweep steps [32 c, 32 c + 32); lane = symbol ----
-        float pre[CH];
-        auto issue = [&](int c) {
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const int k = c * CH + i;
-                pre[i] = (lane < V && k < Tb) ? lp[((size_t)(t0 + k * dt) * B + b) * V + lane] : -INFINITY;
-            }
-        };
-        issue(0);
-        for (int c = 0; c < nchunk; ++c) {
-            if (c >= 2 && !wait_ge(L.cchunk, c - 1, L.bad)) break;       // buffer c & 1 held chunk c - 2: the compute wave has moved on to c - 1
-            float* dst = &L.pbuf[c & 1][0][0];
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                // p = 2^x, x = lp * log2(e) formed in fp64 (an fp32 product would lose 2e-6 at lp = -30): fractional part through
-                // v_exp_f32, integer part by ldexp; below 2^-126 the result is 0 (see the header)
-                const double x = (double)pre[i] * 1.4426950408889634;
-                const double xi = floor(x);
-                const float fr = __builtin_amdgcn_exp2f((float)(x - xi));
-                dst[i * 64 + lane] = (pre[i] > -200.f) ? ldexpf(fr, (int)xi) : 0.f;
-            }
-            if (c + 1 < nchunk) issue(c + 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) LIN_SET(L.fed, c + 1);
-        }
-    } else if (w >= 2) {
-        // ---- storers: frame f = sw, sw + 3, ..: (a, e) of the lane's four states -> log offsets from the row reference ----
-        const int sw = w - 2;
-        float* out = (ROLE == 0 ? ws.alpha : ws.beta) + (size_t)b * T * ws.SP;
-        double* outmax = (ROLE == 0 ? ws.amax : ws.bmax) + (size_t)b * T;
-        for (int f = sw; f < Tb; f += NSTORE) {
-            if (!wait_ge(L.done, f + 1, L.bad)) break;
-            const int slot = f % RING;
-            const pgasr_f4 av = *reinterpret_cast<const pgasr_f4*>(&L.ring_a[slot][lane][0]);
-            const int e = L.ring_e[slot][lane];
-            double lg[4];
-            double ml = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float v = av[j];
-                const int kx = __builtin_amdgcn_frexp_expf(v);
-                const float fm = __builtin_amdgcn_frexp_mantf(v);                          // [0.5, 1)
-                const double l2 = (double)(kx + e) + (double)__builtin_amdgcn_logf(fm);    // v_log_f32 = log2
-                lg[j] = (v > 0.f) ? l2 * 0.6931471805599453 : -INFINITY;
-                ml = fmax(ml, lg[j]);
-            }
-            const double mw = (double)wave_max_f32_all((float)ml);
-            const double m = (mw == -INFINITY) ? 0.0 : mw;
-            const int t_row = t0 + f * dt;
-            if (4 * lane < ws.SP) {
-                pgasr_f4 o = {(float)(lg[0] - m), (float)(lg[1] - m), (float)(lg[2] - m), (float)(lg[3] - m)};
-                *reinterpret_cast<pgasr_f4*>(out + (size_t)t_row * ws.SP + 4 * lane) = o;
-            }
-            if (lane == 0) { outmax[t_row] = m; LIN_SET(L.st[sw], f + 1); }
-        }
-    } else {
-        // ---- compute wave ----
-        const int s0 = 4 * lane;
-        int lab[4]; float skd[4]; bool val[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int s = s0 + j;
-            val[j] = s < S; lab[j] = blank; skd[j] = 0.f;
-            if (val[j] && (s & 1)) {
-                const int l = tgt[s >> 1];
-                lab[j] = (l < 0 || l >= V) ? blank : l;
-                if (ROLE == 0) { if (s >= 3 && tgt[s >> 1] != tgt[(s >> 1) - 1]) skd[j] = 1.f; }
-                else           { if (s + 2 < S && tgt[(s >> 1) + 1] != tgt[s >> 1]) skd[j] = 1.f; }
-            }
-        }
-        auto pget = [&](int k, float (&p)[4]) {          // probabilities of this lane's states at sweep step k (chunk k / 32 must be fed)
-            const float* src = &L.pbuf[(k / CH) & 1][k % CH][0];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) p[j] = val[j] ? src[lab[j]] : 0.f;
-        };
-        float a[4] = {0.f, 0.f, 0.f, 0.f};
-        int e = 0;
-        float scale = 0.f;            // 2^(upstream neighbour's exponent - this lane's): what its two hand-over states are multiplied by
-        float pn[4];
-        // ALIGNMENT (every fourth frame, never on a frame's critical path otherwise): each lane brings its largest value back to [0.5, 1);
-        // empty lanes copy the exponent of the mass side (two hops: mass advances at most two lanes in four frames), so that mass arriving
-        // later lands in a sensible exponent; a lane more than 2^REBASE below its upstream neighbour re-bases itself on that neighbour's
-        // exponent (what it held is below the resolution of what will flow in) -- repeated until no lane is, because a re-base changes the
-        // exponent the NEXT lane sees; finally every lane fixes the factor for its neighbour's hand-over values.  Between alignments the
-        // exponents are frozen: values may grow by 3 * 2^REBASE per frame and lane (< 2^127 over four frames), or shrink (a frame
-        // probability below ~2^-30 four frames in a row flushes a lane: see the header).
-        auto dpp_i = [&](int v) { return ROLE == 0 ? __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true) : __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, true); };
-        auto align = [&]() {
-            const float m = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
-            const int kx = __builtin_amdgcn_frexp_expf(m);            // 0 for m == 0
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = ldexpf(a[j], -kx);
-            e += kx;
-            int ev = m > 0.f ? 1 : 0;                                 // is this lane's exponent meaningful?
-#pragma unroll
-            for (int hop = 0; hop < 2; ++hop) {
-                const int enb = dpp_i(e), evn = dpp_i(ev);
-                if (!ev && evn) { e = enb; ev = 1; }
-            }
-            for (int it = 0; it < 64; ++it) {
-                const int enb = dpp_i(e), evn = dpp_i(ev);
-                const int d = (evn && enb - e > REBASE) ? enb - e : 0;
-                if (!__any(d != 0)) break;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a[j] = ldexpf(a[j], -d);
-                e += d; ev |= (d != 0);
-            }
-            const int enb = dpp_i(e), evn = dpp_i(ev);
-            int sh = evn ? enb - e : 0;
-            sh = sh < -140 ? -140 : sh;
-            scale = (diag & 4) ? 1.f : ldexpf(1.f, sh);               // diag bit 2, timing only
-        };
-        bool ok = wait_ge(L.fed, 1, L.bad);
-        if (ok) {
-            pget(0, pn);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int s = s0 + j;
-                if (ROLE == 0) { if (s <= 1) a[j] = pn[j]; }
-                else           { if (s >= S - 2) a[j] = pn[j]; }       // pn is 0 past S
-            }
-            align();
-        }
-        auto put_row = [&](int k) {
-            if (diag & 1) { if (lane == 0 && k == 0) LIN_SET(L.done, Tb); return; }      // timing only: no rows (the storers run through stale LDS)
-            const int slot = k % RING;
-            *reinterpret_cast<pgasr_f4*>(&L.ring_a[slot][lane][0]) = (pgasr_f4){a[0], a[1], a[2], a[3]};
-            L.ring_e[slot][lane] = e;
-            if (lane == 0) LIN_SET(L.done, k + 1);          // LDS operations of one wave execute in order: the row is written first
-        };
-        if (ok) { put_row(0); if (Tb > 1) pget(1, pn); }
-        // one frame: hand-over (DPP) -> scale -> add -> fma -> mul.  The probabilities of the NEXT frame are fetched behind this frame's
-        // arithmetic and row write, so nothing in a frame waits for an LDS read it has just issued.
-        auto frame = [&](const int k, const bool fetch_next) {
-            float nb1, nb2;
-            if (diag & 8) { nb1 = a[1]; nb2 = a[2]; }                // timing only: no cross-lane hand-off
-            else if (ROLE == 0) { nb1 = dpp_f<0x138>(a[3]); nb2 = dpp_f<0x138>(a[2]); }
-            else                { nb1 = dpp_f<0x130>(a[0]); nb2 = dpp_f<0x130>(a[1]); }
-            nb1 *= scale; nb2 *= scale;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this frame's probabilities (fetched a frame ago) and the last row's writes
-            float n[4];
-            if (ROLE == 0) {
-                n[0] = (a[0] + nb1) * pn[0];                              // even states (blanks) never skip
-                n[1] = fmaf(skd[1], nb1, a[1] + a[0]) * pn[1];
-                n[2] = (a[2] + a[1]) * pn[2];
-                n[3] = fmaf(skd[3], a[1], a[3] + a[2]) * pn[3];
-            } else {
-                n[3] = fmaf(skd[3], nb2, a[3] + nb1) * pn[3];
-                n[2] = (a[2] + a[3]) * pn[2];
-                n[1] = fmaf(skd[1], a[3], a[1] + a[2]) * pn[1];
-                n[0] = (a[0] + a[1]) * pn[0];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = n[j];
-            if ((k & 3) == 0) align();
-            put_row(k);
-            if (fetch_next && !(diag & 2)) pget(k + 1, pn);          // diag bit 1, timing only: the first frame's probabilities for every frame
-        };
-        const long long dg_c0 = (diag & 96) ? clock64() : 0, dg_r0 = (diag & 96) ? wall_clock64() : 0;
-        // frames in blocks of eight: ring space and emission chunks are checked once per block, a frame itself carries no test
-        for (int k0 = 0; k0 < Tb && ok; k0 += 8) {
-            const int kend = k0 + 8 < Tb ? k0 + 8 : Tb;               // frames [max(k0, 1), kend); the last one fetches frame kend
-            if (kend < Tb && !wait_ge(L.fed, kend / CH + 1, L.bad)) { ok = false; break; }     // the chunk of the frame fetched last in this block
-            if (k0 % CH == 0 && lane == 0) LIN_SET(L.cchunk, k0 / CH);   // every read of the chunk before was issued (LDS in order): the feeder may refill it
-            if (kend > RING) {                                         // rows up to kend - 1 reuse the slots of frames < kend - RING: those must be stored
-                const int need = kend - RING - 2;                      // st + 2 >= X  <=>  every frame of that storer below X is stored
-                for (int i = 0; i < NSTORE; ++i) ok = ok && wait_ge(L.st[i], need, L.bad);
-                if (!ok) break;
-            }
-            for (int k = k0 > 0 ? k0 : 1; k < kend; ++k) frame(k, k + 1 < Tb);
-        }
-        // total likelihood from the last row (this wave's own LDS writes): alpha_{T-1}(S-1) + alpha_{T-1}(S-2) = beta_0(0) + beta_0(1)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) {
-            double ll = -INFINITY;
-            bool redo = !ok || LIN_GET(L.bad) != 0;
-            if (!redo && !(diag & 1)) {
-                const int slot = (Tb - 1) % RING;
-                double x[2] = {-INFINITY, -INFINITY};
-                for (int i = 0; i < 2; ++i) {
-                    const int s = (ROLE == 0) ? S - 1 - i : i;
-                    if (s < 0 || s >= S) continue;
-                    const float v = L.ring_a[slot][s >> 2][s & 3];
-                    if (v > 0.f) x[i] = log((double)v) + (double)L.ring_e[slot][s >> 2] * 0.6931471805599453;
-                }
-                const double mx = fmax(x[0], x[1]);
-                ll = (mx == -INFINITY) ? -INFINITY : mx + log(exp(x[0] - mx) + exp(x[1] - mx));
-                // an empty lattice although the alignment is feasible (T >= L + repeats): a frame probability fell below fp32's range
-                if (ll == -INFINITY) {
-                    int rep = 0;
-                    for (int i = 1; i < Lb; ++i) rep += (tgt[i] == tgt[i - 1]);
-                    redo = Tb >= Lb + rep;
-                }
-            }
-            if (redo) LIN_SET(L.redo, 1);
-            else if (ROLE == 0) { ws.nll64[b] = -ll; nll_out[b] = (float)(-ll); }
-            // timing only: shader-clock cycles (bit 5) / 100 MHz ticks x 100 (bit 6) per frame of this wave instead of the nll
-            if (ROLE == 0 && (diag & 32)) nll_out[b] = (float)(clock64() - dg_c0) / (float)Tb;
-            if (ROLE == 0 && (diag & 64)) nll_out[b] = 100.f * (float)(wall_clock64() - dg_r0) / (float)Tb;
-        }
-    }
-    __syncthreads();
-    return LIN_GET(L.redo) != 0;
-}
-
-__global__ __launch_bounds__(lin::THREADS) void ctc_lattice_lin_kernel(
-    const float* __restrict__ lp, const int32_t* __restrict__ targets,
-    const int32_t* __restrict__ in_len, const int32_t* __restrict__ tg_len,
-    int T, int B, int V, int Lmax, int Smax, int blank, CtcWs ws, float* __restrict__ nll_out, int diag) {
-    extern __shared__ __attribute__((aligned(32))) unsigned char lin_smem[];
-    lin::Lds& L = *reinterpret_cast<lin::Lds*>(lin_smem);
-    const int role = blockIdx.y;
-    if (role == 0) {
-        if (ctc_lattice_lin_body<0>(lp, targets, in_len, tg_len, T, B, V, Lmax, blank, ws, nll_out, L, diag) || (diag & 16))
-            ctc_lattice_body<1, 0>(lp, targets, in_len, tg_len, T, B, V, Lmax, Smax, blank, ws, nll_out);
-    } else if (role == 1) {
-        if (ctc_lattice_lin_body<1>(lp, targets, in_len, tg_len, T, B, V, Lmax, blank, ws, nll_out, L, diag) || (diag & 16))
-            ctc_lattice_body<1, 1>(lp, targets, in_len, tg_len, T, B, V, Lmax, Smax, blank, ws, nll_out);
-    } else ctc_labels_body(targets, tg_len, V, Lmax, Smax, blank, ws);
-}
-static_assert(lin::THREADS == CTC_THREADS + 64, "the log-space body and ctc_labels_body run with the launch geometry of either lattice kernel");
-
 // one wave per (t,b)
 __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const float* __restrict__ lp, const int32_t* __restrict__ in_len, const int32_t* __restrict__ tg_len,
@@ -685,15 +394,7 @@ extern "C" int pgasr_ctc_loss_grad(const float* log_probs, const int32_t* target
     // one wave's fp64 VALU issue rate, not the barrier, is then the limit)
 #define PGASR_LATTICE(NSPT) PGASR_LAUNCH_KERNEL(ctc_lattice_kernel<NSPT>, dim3(B, 3), dim3(CTC_THREADS + 64), 0, st, \
                         log_probs, targets, input_lengths, target_lengths, T, B, V, Lmax > 0 ? Lmax : 1, Smax, blank, ws, nll, 0)
-    // S <= 256: the linear-domain kernel (PGASR_CTC_LIN=0 keeps the log-space kernel: A/B and fall-back)
-    const char* elin = getenv("PGASR_CTC_LIN");
-    if (Smax <= 4 * 64 && !(elin && elin[0] == '0')) {
-        if (hipFuncSetAttribute((const void*)ctc_lattice_lin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lin::Lds)) != hipSuccess)
-            return PGASR_ERR_LAUNCH;
-        PGASR_LAUNCH_KERNEL(ctc_lattice_lin_kernel, dim3(B, 3), dim3(lin::THREADS), sizeof(lin::Lds), st,
-                            log_probs, targets, input_lengths, target_lengths, T, B, V, Lmax > 0 ? Lmax : 1, Smax, blank, ws, nll,
-                            getenv("PGASR_CTC_LIN_DIAG") ? atoi(getenv("PGASR_CTC_LIN_DIAG")) : 0);
-    } else if (Smax <= CTC_THREADS) PGASR_LATTICE(1);
+    if (Smax <= CTC_THREADS) PGASR_LATTICE(1);
     else if (Smax <= 2 * CTC_THREADS) PGASR_LATTICE(2);
     else if (Smax <= 4 * CTC_THREADS) PGASR_LATTICE(4);
     else PGASR_LATTICE(8);
