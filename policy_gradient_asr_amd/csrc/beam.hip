@@ -309,7 +309,10 @@ inline size_t beam_lds_bytes(int K, int V) {
 //   frames are staged 32 at a time through LDS, two chunks ahead in registers, so no load is ever waited for.
 // =====================================================================================================================
 #ifdef PGASR_BEAM_DIAG
-__device__ unsigned long long beam_diag_counters[4];      // frames, frames redone by the exact rounds, -, -
+__device__ unsigned long long beam_diag_counters[4];      // frames, frames redone by the exact rounds, hash-table probes, longest probe chain
+#endif
+#ifndef PGASR_BEAM_UNROLL
+#define PGASR_BEAM_UNROLL 1
 #endif
 namespace sb {
 constexpr int K_MAX = 16, V_MAX = 32, H = 32768, CH = 32;
@@ -378,6 +381,10 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
     int Tb = lengths ? lengths[b] : T; Tb = Tb < 0 ? 0 : (Tb > T ? T : Tb);
 
     for (int i = lane; i < H / 4; i += 64) reinterpret_cast<uint4*>(table)[i] = make_uint4(0u, 0u, 0u, 0u);
+#ifdef PGASR_BEAM_DIAG
+    const long long dg_c0_ = clock64();
+    const bool getenv_cycles_ = (collapse & 2) != 0;      // diagnostic: flags bit 2 of the entry point -> out_score = cycles per frame
+#endif
 
     // entry state, replicated per row
     double pb = (j == 0) ? 0.0 : -INFINITY, pnb = -INFINITY, tot = (j == 0) ? 0.0 : -INFINITY;
@@ -401,6 +408,8 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
     };
     issue(0); commit(0); issue(CH);
     __syncthreads();
+    bool tied_last = false;      // the previous frame needed the exact rounds: two beam entries with bit-identical totals stay tied for as long as both
+                                 // live (every extension of one meets the same extension of the other), so the speculative rounds are skipped
 
     for (int t = 0; t < Tb; ++t) {
         if ((t & (CH - 1)) == 0 && t > 0) {          // chunk boundary: the next chunk's rows have long arrived
@@ -482,8 +491,12 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
         // leaves behind -- which lane won (s_ff1 of the mask -> v_writelane into lane r) and a won-bit per lane -- is scalar work off
         // the chain; the winners' identities are put together AFTER the rounds: lane r fetches its winner lane's won-bits and sort
         // permutation with two ds_bpermute and finds the slot as the (number of earlier wins of that lane)-th of its sorted list.
-        // A round in which two lanes share the maximal high word (equal to 2^-20 relative: ~1e-4 of the frames on real scores;
-        // always with -inf scores) makes both pop: the scalar tallies disagree and the frame is redone by the exact loop below.
+        // A round in which two lanes share the maximal high word (equal to 2^-20 relative) makes both pop: the scalar tallies disagree and
+        // the frame is redone by the exact loop below -- 0.1-0.8 % of the frames on random and model-like log-probs (make beamdiag,
+        // tools/dev/r5_beam_ties.py).  Except: two beam entries with BIT-IDENTICAL totals stay tied for as long as both live (every extension of
+        // one meets the same extension of the other); one such utterance of 32 fell back in 871 of its 1000 frames and set the kernel's time
+        // (5.47 ms against 4.07 for the same distribution with another seed).  So a frame that follows a tied frame goes straight to the exact
+        // rounds (tied_last), and those use the vector-only all-reduce as well: 4.71 ms on that data (tools/dev/r5_beam_var.py).
         // (Measured and not kept in round 4: TWO winners per round from one all-reduce over (first, second) pairs of high words.)
         unsigned packed = 0u;
         int nnew = 0;
@@ -494,8 +507,14 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
             for (int d = 0; d < 8; ++d) { hq[d] = (unsigned)(k[d] >> 32); perm |= (((unsigned)k[d] >> 4) & 7u) << (3 * d); }
             unsigned won = 0u, wl_of = 0u;
             int pops = 0, rounds = 0;
-#define SB_ROUND(r)                                                                                                  \
-            if (K > (r)) {                                                                                               \
+            bool need_exact = tied_last;                        // straight to the exact rounds
+            if (!need_exact) {
+            // sixteen rounds written out (default) or a rolled loop (-DPGASR_BEAM_UNROLL=0): written out, the compiler keeps a 64-bit "K > r" mask
+            // per round alive across the frame loop (106 SGPRs) -- but the rolled loop is no faster: same box, A/B/A/B by library
+            // (tools/dev/r5_beam_unroll.sh), beam 16 flat 3.37 written out / 3.55 rolled, peaked 3.91 / 4.09, beam 5 2.34 / 2.29
+#if PGASR_BEAM_UNROLL
+#define SB_ROUND_BODY(r, RC)                                                                                             \
+            {                                                                                                            \
                 const unsigned hh = hq[0];                                                                               \
                 const unsigned smax = wave_allmax_valu(hh);                                                              \
                 const bool win = (hh == smax) && (smax != 0u);                                                           \
@@ -503,17 +522,39 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
                 pops += __popcll(m); rounds += (m != 0ull) ? 1 : 0;                                                      \
                 {   /* lane r of wl_of := the winner lane (a scalar); v_writelane has no builtin in this compiler */     \
                     const int wls = __ffsll((long long)m) - 1;                                                           \
-                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(wl_of) : "s"(wls), "n"(r));                         \
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(wl_of) : "s"(wls), RC(r));                          \
                 }                                                                                                        \
                 won |= win ? (1u << (r)) : 0u;                                                                           \
                 _Pragma("unroll") for (int d = 0; d < 7; ++d) hq[d] = win ? hq[d + 1] : hq[d];                           \
                 hq[7] = win ? 0u : hq[7];                                                                                \
             }
+#define SB_ROUND(r) if (K > (r)) SB_ROUND_BODY(r, "n")
             SB_ROUND(0) SB_ROUND(1) SB_ROUND(2) SB_ROUND(3) SB_ROUND(4) SB_ROUND(5) SB_ROUND(6) SB_ROUND(7)
             SB_ROUND(8) SB_ROUND(9) SB_ROUND(10) SB_ROUND(11) SB_ROUND(12) SB_ROUND(13) SB_ROUND(14) SB_ROUND(15)
 #undef SB_ROUND
             static_assert(K_MAX == 16, "sixteen rounds are written out");
-            if (pops == rounds) {
+#else
+#pragma unroll 1
+            for (int r = 0; r < K; ++r) {
+                const unsigned hh = hq[0];
+                const unsigned smax = wave_allmax_valu(hh);
+                const bool win = (hh == smax) && (smax != 0u);
+                const unsigned long long m = __ballot(win);
+                pops += __popcll(m); rounds += (m != 0ull) ? 1 : 0;
+                {   // lane r of wl_of := the winner lane (a scalar); v_writelane has no builtin in this compiler
+                    const int wls = __ffsll((long long)m) - 1;
+                    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(wl_of) : "s"(wls), "s"(r) : "m0");      // two scalar operands: the lane select goes through M0
+                }
+                won |= win ? (1u << r) : 0u;
+#pragma unroll
+                for (int d = 0; d < 7; ++d) hq[d] = win ? hq[d + 1] : hq[d];
+                hq[7] = win ? 0u : hq[7];
+            }
+#endif
+                need_exact = pops != rounds;
+            }
+            tied_last = false;
+            if (!need_exact) {
                 nnew = rounds;
                 const unsigned wl = row0_to_all(wl_of);                       // lane (q, j): the winner lane of round j
                 const unsigned wwon = (unsigned)__shfl((int)won, (int)(wl & 63u), 64);
@@ -529,12 +570,13 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
                 for (int r = 0; r < K; ++r) {
                     const unsigned long long head = k[0];
                     const unsigned hh = (unsigned)(head >> 32);
-                    const unsigned smax = wave_allmax(hh);
+                    const unsigned smax = wave_allmax_valu(hh);
                     if (smax == 0u) break;
                     unsigned long long m = __ballot(hh == smax);
                     if (__popcll(m) != 1) {
+                        tied_last = true;
                         const unsigned ll = (hh == smax) ? (unsigned)head : 0u;
-                        const unsigned smaxlo = wave_allmax(ll);
+                        const unsigned smaxlo = wave_allmax_valu(ll);
                         m = __ballot(hh == smax && (unsigned)head == smaxlo);
                     }
                     const int wl = __ffsll((long long)m) - 1;
@@ -573,15 +615,25 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
             else {
                 // canonical node of (parent id, symbol): find, else insert
                 const unsigned key = ((g_id << 8) | (unsigned)s) + 1u;
-                unsigned h = (key * 2654435761u) >> 17;
+                // Triangular probing (h + 1, + 2, + 3, ..: visits every slot of a power-of-two table) behind a two-round mix.  Round 5: the table
+                // holds every prefix an utterance ever had in its beam (up to T * beam of 32768 slots), and with linear probing behind one
+                // multiplicative round the chains clustered -- up to 24-30 probes, each a dependent LDS round trip the whole wave waits for,
+                // and the kernel's time followed the unluckiest utterance (same distribution, other seed: 4.07 against 5.47 ms at beam 16).
+                unsigned h = key * 2654435761u;
+                h ^= h >> 15; h *= 0x2C1B3C6Du;
+                h >>= 17;
                 for (int guard = 0; guard < H; ++guard) {
+#ifdef PGASR_BEAM_DIAG
+                    atomicAdd(&beam_diag_counters[2], 1ull);
+                    atomicMax(&beam_diag_counters[3], (unsigned long long)(guard + 1));
+#endif
                     const unsigned v = table[h];
                     if ((v & KEYMASK) == key) { n_id = h; break; }
                     if (v == 0u) {
                         const unsigned old = atomicCAS(&table[h], 0u, key);
                         if (old == 0u || (old & KEYMASK) == key) { n_id = h; break; }
                     }
-                    h = (h + 1u) & (unsigned)(H - 1);
+                    h = (h + (unsigned)guard + 1u) & (unsigned)(H - 1);
                 }
             }
         }
@@ -623,7 +675,7 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
         int tok = 0; bool keep = false;
         if (i < n) {
             tok = tmp[n - 1 - i];
-            keep = !collapse || i == 0 || tok != (int)tmp[n - i];
+            keep = !(collapse & 1) || i == 0 || tok != (int)tmp[n - i];
         }
         const unsigned long long m = __ballot(keep);
         if (keep) o[outn + __popcll(m & ((1ull << lane) - 1ull))] = tok;
@@ -633,6 +685,9 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
         out_len[b] = outn;
         const double t0 = __shfl(tot, 0, 64);
         out_score[b] = (Tb > 0) ? -t0 : -0.0;
+#ifdef PGASR_BEAM_DIAG
+        if (getenv_cycles_) out_score[b] = (double)(clock64() - dg_c0_) / (double)(Tb > 0 ? Tb : 1);      // cycles per frame of this utterance
+#endif
     }
 }
 #undef SB_CE
@@ -665,7 +720,11 @@ extern "C" int pgasr_ctc_beam_search(const void* log_probs, int is_f64, long lon
     if (!workspace || workspace_bytes < need) return PGASR_ERR_WORKSPACE;
     if ((long long)T * beam + 1 >= (1ll << 24)) return PGASR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+#ifdef PGASR_BEAM_DIAG
+    const int collapse = (flags & 1) | ((flags & 4) ? 2 : 0);
+#else
     const int collapse = flags & 1;
+#endif
     if (!is_f64 && !(flags & 2) && beam <= sb::K_MAX && V <= sb::V_MAX && (long long)T * beam <= sb::MAX_NODES && T <= sb::MAX_TOKENS) {
         // training path: one wave per utterance, trie and candidate lists in LDS, no workspace traffic
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sb::beam_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb::LDS_BYTES);

@@ -14,6 +14,14 @@ cases["randn*0.05 (flat)"] = torch.log_softmax(torch.randn(T, B, V, generator=g)
 x = torch.randn(T * B, K, generator=g).to(dev); w = (torch.randn(V, K, generator=g) * 0.05).to(dev); bias = torch.full((V,), 0.1, device=dev)
 cases["head kernel on random x (model-like)"] = hipops.head_logsoftmax(x, w, bias)[1].view(T, B, V)
 cnt = (ctypes.c_ulonglong * 4)()
+have = hasattr(lib, "pgasr_diag_beam_counters")
+try:
+    lib.pgasr_diag_beam_counters
+except AttributeError:
+    have = False
+    class _Nop:
+        def pgasr_diag_beam_counters(self, *a): return 0
+    lib = _Nop()
 for name, lp in cases.items():
     for beam in (16, 5):
         hipops.ctc_beam_search(lp, None, beam=beam); torch.cuda.synchronize()
@@ -22,4 +30,5 @@ for name, lp in cases.items():
         e0.record(); hipops.ctc_beam_search(lp, None, beam=beam); e1.record(); torch.cuda.synchronize()
         lib.pgasr_diag_beam_counters(cnt, 1)
         print(json.dumps({"log_probs": name, "beam": beam, "ms": round(e0.elapsed_time(e1), 3), "frames": cnt[0], "frames_redone": cnt[1],
-                          "fraction": round(cnt[1] / max(cnt[0], 1), 4)}), flush=True)
+                          "fraction": round(cnt[1] / max(cnt[0], 1), 4),
+                          "table_probes_per_frame": round(cnt[2] / max(cnt[0], 1), 2), "longest_probe_chain": cnt[3]}), flush=True)
