@@ -402,8 +402,9 @@ def gemm_probe(precision, reps=5):
 
     out = {}
     pmc = {}
-    try:       # optional evidence written by tools/profile_round4.sh (never required to run)
-        with open(os.path.join(ROOT, "profiles", "r04_gemm_pmc.json")) as fi:
+    try:       # optional evidence written by tools/profile_round5.sh (round 4: profile_round4.sh); never required to run
+        gp = next(f for f in ("r05_gemm_pmc.json", "r04_gemm_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        with open(os.path.join(ROOT, "profiles", gp)) as fi:
             pmc = json.load(fi)
     except Exception:  # noqa: BLE001
         pmc = {}

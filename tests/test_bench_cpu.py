@@ -81,15 +81,15 @@ def test_roofline_record_counts_launches_per_sampled_step():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r04_bench.json is one line of `python bench.py` on an MI355X (default precision f32): the driver's contract fields, the
+    """profiles/r05_bench.json is one line of `python bench.py` on an MI355X (default precision f32): the driver's contract fields, the
     roofline (latency-bound sweep with its hand-off floor), the MFMA-bound kernels' roofline_gemm, the CPU baseline and the round's extra
-    legs are all there and consistent with each other; profiles/r04_bench_bf16x3.json is the same command with --precision bf16x3."""
+    legs are all there and consistent with each other; profiles/r05_bench_bf16x3.json is the same command with --precision bf16x3."""
     import json
-    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "roofline_gemm", "cpu_baseline"):
         assert k in d, k
-    assert d["metric"] == bench.METRIC and d["dtype"].startswith("f32")
+    assert d["metric"] == bench.METRIC and d["dtype"].startswith("f32") and d["precision"] == "f32"
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6           # utterances/sec of B = 32 per GPU
     assert "workload" in d["config"] and "model" not in d["config"]
@@ -116,11 +116,12 @@ def test_committed_bench_line_keeps_the_contract():
     pv = d["precision_variants"]
     assert pv["f32"]["max_rel_err_vs_fp64"]["param_grads_frobenius"] < pv["bf16x3"]["max_rel_err_vs_fp64"]["param_grads_frobenius"] < 1e-3
     assert pv["f32"]["ms_per_step"] <= 11.0 and pv["bf16x3"]["ms_per_step"] < pv["f32"]["ms_per_step"]
-    b = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_bf16x3.json")))
+    b = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_bf16x3.json")))
     assert b["dtype"].startswith("bf16x3") and abs(b["roofline"]["peak"] - 2500.0 / 3) < 1e-9 and b["roofline_gemm"]["products_per_flop"] == 3
-    assert b["ms_per_step"] < d["ms_per_step"]
+    assert b["ms_per_step"] < d["ms_per_step"] and b["precision"] == "bf16x3"
+    assert d["bucketed"]["ms_per_step"] < 12.6            # configs[4]: the beam-16 reward hypothesis (round 4: 13.06 ms)
     # the N > 1 plumbing rehearsal (two ranks on ONE GPU over gloo) ran every leg with world 2 and says what it is
-    reh = json.load(open(os.path.join(ROOT, "profiles", "r04_rehearse.json")))
+    reh = json.load(open(os.path.join(ROOT, "profiles", "r05_rehearse.json")))
     assert reh["n_gpus"] == 2 and reh["rccl_world_size"] == 2 and "NOT a scaling number" in reh["collective_backend"]
     for leg in ("long_run", "inputs_resident", "bucketed"):
         assert reh[leg]["ms_per_step"] > 0
