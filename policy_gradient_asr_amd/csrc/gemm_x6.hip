@@ -148,10 +148,14 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;      // (w made wave-uniform for the compiler -- readfirstlane -- spills: measured, not kept)
     const int wm = w >> 2, wn = w & 3;
     const int nk = g.K / TK;
-    if (FEED && g.xcc_busy) {       // a workgroup on one of the sweep's XCDs leaves at once (placement is read, not assumed)
+    bool head_only = false;         // a workgroup on one of the sweep's XCDs (placement is read, not assumed) ..
+    if (FEED && g.xcc_busy) {
         const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;
-        if (__hip_atomic_load(g.xcc_busy + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-    }
+        if (__hip_atomic_load(g.xcc_busy + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            if (!g.head_help) return;       // .. leaves at once,
+            head_only = true;               // .. or (round 5, PGASR_X6_HEAD_HELP) helps with the K-split head items first: the eleven CUs per XCD that a
+        }                                   // sweep leaves idle are free the moment it starts, while the free XCDs' CUs may still belong to the layer above's
+    }                                       // weight-gradient workgroups -- and a sweep that waits for its first rows has no L2 traffic to disturb
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   for (;;) {
     int tbx, tby;
@@ -159,11 +163,16 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
     unsigned tile = 0;
     if (FEED) {
         unsigned* mailbox = reinterpret_cast<unsigned*>(smem + LDS_BYTES);
-        if (tid == 0) *mailbox = __hip_atomic_fetch_add(g.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned S = (unsigned)g.split_tiles, ntot = (unsigned)g.mt_count * (unsigned)g.nt_count;
+        if (tid == 0) {
+            // a head-only workgroup looks before it draws: past the head it leaves without taking an item (a late look may still draw one
+            // whole tile: harmless)
+            if (head_only && __hip_atomic_load(g.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 4u * S) *mailbox = 0xFFFFFFFFu;
+            else *mailbox = __hip_atomic_fetch_add(g.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
         const unsigned t = *mailbox;
         __syncthreads();
-        const unsigned S = (unsigned)g.split_tiles, ntot = (unsigned)g.mt_count * (unsigned)g.nt_count;
         if (t >= ntot + 3u * S) return;             // 4 S quarter items, then the remaining ntot - S whole tiles
         if (t < 4u * S) { tile = t >> 2; qpart = (int)(t & 3u); kt0 = qpart * (nk >> 2); kt1 = kt0 + (nk >> 2); }
         else tile = t - 3u * S;
@@ -806,6 +815,10 @@ __global__ __launch_bounds__(256) void pack_x6w_kernel(const float* __restrict__
     blk[1024] = (u32x4_t){l[0], l[1], l[2], l[3]};
 }
 
+// Workgroups of a feed that land on the sweep's own XCDs take K-split head items before they leave (PGASR_X6_HEAD_HELP=0: they leave at once).
+// Round 5, tools/dev/r5_head_help.sh, A/B/A/B on one box: fed backward sweeps 1.64-1.66 -> 1.61-1.63 ms, f32 step 10.05-10.10 -> 10.02 ms.  Small,
+// because the stall only moves: the tiles behind the head still wait for the free XCDs' CUs (NOTES 0.2).
+constexpr int X6_HEAD_HELP_DEFAULT = 1;
 constexpr int X6_FEED_SPLIT_MAX = 128;     // split tiles per feed at most: 4 x 128 slabs of 256 KB = 128 MB of workspace (arrival counters: words 64..191 of the head)
 // Time-ordered tile groups (of nt tiles) at the head of a feed whose tiles are split into K-quarters (PGASR_X6_SPLIT_GROUPS, read at every
 // call; the fed and the sequential order read the same value, so they keep giving the same bits).
@@ -919,6 +932,10 @@ extern "C" int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int 
     }
     DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, nullptr, 0.f, (unsigned*)workspace, xcc_busy, tiles_done, mt, nt, order,
                   quarters, split, (float*)((char*)workspace + 1024), (unsigned*)workspace + 64, 0, Wmid};
+    {   // PGASR_X6_HEAD_HELP (read at every call; a speed hint, the same bits either way): workgroups on the sweep's XCDs take K-split head items
+        const char* eh = getenv("PGASR_X6_HEAD_HELP");
+        g.head_help = (eh ? atoi(eh) : X6_HEAD_HELP_DEFAULT) != 0 && split > 0;
+    }
     for (int pass = 0; pass < 2; ++pass) {     // one persistent workgroup per CU; pass 1 ignores the busy counters
         if (pass == 1) g.xcc_busy = nullptr;
         PGASR_LAUNCH_KERNEL(kern, dim3(256), dim3(x6c::THREADS), lds, st, g);

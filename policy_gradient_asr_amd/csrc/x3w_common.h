@@ -27,6 +27,7 @@ struct DmaGemmArgs {
     unsigned* arrive;           // FEED: [split_tiles] quarters finished (zeroed by the host)
     int single;                 // FEED: every workgroup takes ONE work item and leaves (the head launch in front of a sweep)
     const unsigned short* Wmid; // six-product kernels (gemm_x6.hip): the middle plane of the 3-plane split (hi, mid, lo)
+    int head_help;              // six-product FEED: workgroups on the sweep's own XCDs take K-split head items before they leave (0: they leave at once)
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_base) {
