@@ -367,7 +367,12 @@ __device__ __forceinline__ unsigned wave_allmax(unsigned v) {
     return ab > cd ? ab : cd;
 }
 
-#define SB_CE(a, b) { const unsigned long long x_ = k[a], y_ = k[b]; const bool sw_ = x_ < y_; k[a] = sw_ ? y_ : x_; k[b] = sw_ ? x_ : y_; }
+// one 64-bit compare and four 32-bit selects per exchange (written as selects of 64-bit values the compiler emits a second compare, v_cmp_gt_u64
+// beside v_cmp_lt_u64, for the other output: 19 more half-rate instructions per frame)
+#define SB_CE(a, b) { const unsigned long long x_ = k[a], y_ = k[b]; const bool sw_ = x_ < y_;                                  \
+                      const unsigned xl_ = (unsigned)x_, xh_ = (unsigned)(x_ >> 32), yl_ = (unsigned)y_, yh_ = (unsigned)(y_ >> 32);   \
+                      k[a] = ((unsigned long long)(sw_ ? yh_ : xh_) << 32) | (sw_ ? yl_ : xl_);                                    \
+                      k[b] = ((unsigned long long)(sw_ ? xh_ : yh_) << 32) | (sw_ ? xl_ : yl_); }
 
 __global__ __launch_bounds__(64) void beam_small_kernel(
     const float* __restrict__ lp, long long stride_t, long long stride_b, const int32_t* __restrict__ lengths,
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
                 const unsigned hh = hq[0];                                                                               \
                 const unsigned smax = wave_allmax_valu(hh);                                                              \
                 const bool win = (hh == smax) && (smax != 0u);                                                           \
-                const unsigned long long m = __ballot(win);                                                              \
+                const unsigned long long m = __ballot(hh == smax) & __ballot(smax != 0u);   /* two compare masks: no 0/1 round trip */ \
                 pops += __popcll(m); rounds += (m != 0ull) ? 1 : 0;                                                      \
                 {   /* lane r of wl_of := the winner lane (a scalar); v_writelane has no builtin in this compiler */     \
                     const int wls = __ffsll((long long)m) - 1;                                                           \
