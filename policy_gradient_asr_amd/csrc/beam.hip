@@ -353,6 +353,21 @@ __device__ __forceinline__ unsigned wave_allmax_valu(unsigned v) {
     auto c = __builtin_amdgcn_permlane32_swap(v, v, false, false);      // the two halves meet
     return c[0] > c[1] ? c[0] : c[1];
 }
+// the same as ONE scalar: row maxima by DPP rotations, rows 1 / 3 take row 0's / 2's lane 15 (row_bcast:15), rows 2, 3 take lane 31 (row_bcast:31),
+// lane 63 holds the maximum and v_readlane hands it to the scalar unit -- seven dependent instructions instead of ten, the compare that follows
+// takes a scalar operand.  Measured in the pop rounds and NOT used there (round 5): flat 3.19 -> 3.37 ms, peaked 3.68 -> 3.83 at beam 16 -- the trip
+// through the scalar unit costs the chain more than three vector instructions save.  Kept for the diagnostic record only.
+template <int CTRL, int RM> __device__ __forceinline__ unsigned dpp_rows(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, RM, 0xF, false);
+}
+__device__ __forceinline__ unsigned wave_allmax_scalar(unsigned v) {
+    v = row_allmax(v);
+    // the two cross-row steps as fused v_max_u32_dpp (the builtin gives v_mov_b32_dpp + v_max_u32: a row mask other than 0xf is not folded);
+    // rows outside the mask keep their value; the wait states a DPP read behind a vector write needs are written out
+    asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1" : "+v"(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 // row 0's value of v in all four rows
 __device__ __forceinline__ unsigned row0_to_all(unsigned v) {
     auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
