@@ -38,7 +38,8 @@ typedef enum pgasr_status {
 } pgasr_status;
 
 /* 4 (round 3): pgasr_adam_step(guards, applied), pgasr_lstm_pack_weights(planes), the feed phases, and the streamed order:
- * pgasr_lstm_wgrad_slabs, pgasr_lstm_layer_bwd_streamed, pgasr_lstm_wgrads_streamed(+_workspace_bytes), pgasr_stream_gate_sum. */
+ * pgasr_lstm_wgrad_slabs, pgasr_lstm_layer_bwd_streamed, pgasr_lstm_wgrads_streamed(+_workspace_bytes), pgasr_stream_gate_sum.
+ * 7 (round 5): pgasr_stream_gate_report, pgasr_lstm_cell_f32; the sampler's counters for utterances beyond the global batch. */
 #define PGASR_ABI_VERSION 7
 
 int pgasr_abi_version(void);
@@ -303,6 +304,12 @@ int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int lda, const 
  * exponent maxima taken out exactly.  A defined function for parity, not a hot kernel (2 H exponentials per output and frame). */
 int pgasr_attention_ctx(const float* dec, const float* enc, int NQ, int B, int T, int H, float* ctx, void* stream);
 
+/* One step of the decoder's one-layer LSTM (model.py:104,111, Decoder's nn.LSTM(128 -> hidden); gate order i, f, g, o):
+ *   g = gh + xp;  c <- sigmoid(g_f) c + sigmoid(g_i) tanh(g_g);  h <- sigmoid(g_o) tanh(c);  h_out <- h (may be NULL)
+ * gh (B x 4H) = h_{t-1} W_hh^T (pgasr_gemm_f32, exact mode), xp (B x 4H) = x_t W_ih^T + b_ih + b_hh, c and h (B x H) in place.
+ * Forward only, like the reference's decoder. */
+int pgasr_lstm_cell_f32(const float* gh, const float* xp, float* c, float* h, float* h_out, int B, int H, void* stream);
+
 size_t pgasr_colsum_workspace_bytes(int rows, int cols);
 int pgasr_colsum_f32(const float* X, int rows, int cols, int ld, float* out, float* out2, int accumulate,
                      void* workspace, size_t workspace_bytes, void* stream);
@@ -421,7 +428,7 @@ int pgasr_lstm_layer_bwd(float* gates, const float* out, const float* cbuf, cons
 /* STREAMED backward sweep (round 3): the sweep publishes its progress so that the SAME layer's weight-gradient products
  * (pgasr_lstm_wgrads_streamed, on another stream, launched after this call) consume its d(pre-activation) rows while it
  * runs, instead of waiting for its end.  The products are sums over n = pgasr_lstm_wgrad_slabs(T, edges, max) TIME slabs
- * 0 = h_0 < h_1 < .. < h_n = T (sizes 16, 24, 32, 48, 64, 88, 120, 168, 168 .. frames: small where a sweep ends); sweep step s is
+ * 0 = h_0 < h_1 < .. < h_n = T (sizes 16, 24, 32, 40, 48, 64, 80, 104, 128, 128 .. frames: small where a sweep ends); sweep step s is
  * frame T-1-s for direction 0 and frame s for direction 1, so for both directions the sweep steps < T - h_(n-k) complete
  * the first k slabs of the direction's order.  slab_done[c], c = 2 * (16-utterance group) + direction (2 * ceil(B/16)
  * words, zeroed by the caller BEFORE this launch), counts those publications k = 1..n: the rows are then in memory and

@@ -102,6 +102,7 @@ SIGNATURES = {
                                              c_ptr, c_ptr, C.c_int, c_ptr, C.c_size_t, c_ptr]),
     "pgasr_error_flag": (C.c_int, [c_i32p, c_i32p, c_f32p, c_ptr]),
     "pgasr_attention_ctx": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_ptr]),
+    "pgasr_lstm_cell_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, c_ptr]),
     "pgasr_pack_x6w_planes": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr]),
     "pgasr_split_bf16_planes3": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "pgasr_gemm_x6w_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_ptr, c_ptr, c_ptr, c_f32p, C.c_int,

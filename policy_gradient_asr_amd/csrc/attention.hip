@@ -50,7 +50,32 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_ctx_kernel(const float*
     }
     if (k < H) ctx[(size_t)q * H + k] = acc;
 }
+
+// One step of the decoder's LSTM cell (model.py:104,111: nn.LSTM(128 -> hidden), gate order i, f, g, o): the recurrent product
+// gh = h W_hh^T comes from the exact fp32 GEMM, xp = x_t W_ih^T + b_ih + b_hh was made for all steps at once.  Thread = (b, j).
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ gh, const float* __restrict__ xp,
+                                                        float* __restrict__ c, float* __restrict__ h, float* __restrict__ h_out,
+                                                        int B, int H) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * H) return;
+    const int b = idx / H, j = idx - b * H;
+    const size_t g0 = (size_t)b * 4 * H + j;
+    const float gi = gh[g0] + xp[g0], gf = gh[g0 + H] + xp[g0 + H], gg = gh[g0 + 2 * H] + xp[g0 + 2 * H], go = gh[g0 + 3 * H] + xp[g0 + 3 * H];
+    const float i = 1.f / (1.f + expf(-gi)), f = 1.f / (1.f + expf(-gf)), o = 1.f / (1.f + expf(-go));
+    const float cn = f * c[idx] + i * tanhf(gg);
+    const float hn = o * tanhf(cn);
+    c[idx] = cn; h[idx] = hn;
+    if (h_out) h_out[idx] = hn;
+}
 }  // namespace
+
+extern "C" int pgasr_lstm_cell_f32(const float* gh, const float* xp, float* c, float* h, float* h_out, int B, int H, void* stream) {
+    if (!gh || !xp || !c || !h || B <= 0 || H <= 0) return PGASR_ERR_INVALID_ARG;
+    if ((long long)B * H > (1ll << 30)) return PGASR_ERR_UNSUPPORTED;
+    PGASR_LAUNCH_KERNEL(lstm_cell_kernel, dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gh, xp, c, h, h_out, B, H);
+    PGASR_CHECK_LAUNCH();
+    return PGASR_OK;
+}
 
 extern "C" int pgasr_attention_ctx(const float* dec, const float* enc, int NQ, int B, int T, int H, float* ctx, void* stream) {
     if (!dec || !enc || !ctx || NQ <= 0 || B <= 0 || T <= 0 || H <= 0 || (NQ % B)) return PGASR_ERR_INVALID_ARG;

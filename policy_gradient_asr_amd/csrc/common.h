@@ -62,16 +62,24 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 // ---- the K-slabs (time ranges) of a BLSTM layer's weight-gradient products (pgasr_lstm_wgrads_streamed) ----
-// Frames 0 = h_0 < h_1 < .. < h_n = T with slab sizes 16, 24, 32, 48, 64, 88, 120, 168, 168, .. (x 11/8, rounded to 8, capped at 168;
+// Frames 0 = h_0 < h_1 < .. < h_n = T with slab sizes 16, 24, 32, 40, 48, 64, 80, 104, 128, 128, .. (x 5/4, rounded to 8, capped at 128;
 // the last slab takes what is left while that is <= 1.5 sizes).  Direction 0's backward sweep walks DOWN in time, so its tiles use the
 // slabs [h_j, h_j+1) as they are -- the big ones are complete early, the small ones last -- and direction 1's tiles use the mirror
 // image [T - h_j+1, T - h_j).  Either way the slab that is complete after sweep step T - h_j - 1 is the (n - j)-th, so ONE list of
-// publication points P_k = T - h_(n-k), k = 1..n, serves both directions.  Why shrinking slabs: a 256 x 256 tile costs a CU ~3 us per
-// 32 rows (few items in flight: latency bound) while the sweep produces 32 rows in ~1.2 us, so the products run (3 s - 1.2 R) us
-// behind the sweep's end for a slab of s steps with R steps after it: <= ~50 us with these sizes (measured with x 13/8: 112 us;
-// sixteen equal slabs: 185 us).
-// A function of T only -- it DEFINES the summation order of these products in every mode.
-__host__ __device__ inline int pgasr_wslab_next(int s) { const int n = ((s * 11) / 8 + 4) & ~7; return n > 168 ? 168 : n; }
+// publication points P_k = T - h_(n-k), k = 1..n, serves both directions.  Why shrinking slabs: a 256 x 256 tile costs a CU c us per
+// 32 rows (few items in flight: latency bound) while the sweep produces 32 rows in ~1.3 us, so the products run (c s - 1.3 R) us
+// behind the sweep's end for a slab of s steps with R steps after it.  Rounds 3-4 sized them for the bf16x3 kernel (c ~ 3: x 11/8,
+// cap 168, <= ~50 us behind; x 13/8: 112 us; sixteen equal slabs: 185 us).  The six-product kernel of the "f32" mode costs c ~ 5.5, and
+// with x 11/8 / 168 its products ran ~400 us behind the sweep's end -- holding the CUs the NEXT layer's feed wants at the start of its
+// sweep, and lengthening the tail of the step.  Round 5 (tools/dev/r5_slab_sched.sh, f32 step, one box): 11/8 cap 168 9.95-9.99 ms,
+// 5/4 cap 176 9.90, 5/4 cap 128 9.80, 5/4 cap 96 9.82, 11/8 cap 64 9.90 (tail 0.61 -> 0.54 ms); 5/4 cap 128 it is (13 slabs at T = 1000).
+// A function of T only -- it DEFINES the summation order of these products in every mode.  (PGASR_WSLAB_*: A/B builds only, `make variant`.)
+#ifndef PGASR_WSLAB_NUM
+#define PGASR_WSLAB_NUM 5
+#define PGASR_WSLAB_DEN 4
+#define PGASR_WSLAB_CAP 128
+#endif
+__host__ __device__ inline int pgasr_wslab_next(int s) { const int n = ((s * PGASR_WSLAB_NUM) / PGASR_WSLAB_DEN + 4) & ~7; return n > PGASR_WSLAB_CAP ? PGASR_WSLAB_CAP : n; }
 __host__ __device__ inline int pgasr_wslab_count(int T) {
     int h = 0, s = 16, n = 1;
     while (T - h > s + s / 2) { h += s; s = pgasr_wslab_next(s); ++n; }

@@ -696,8 +696,9 @@ def lstm_wgrad_slabs(T):
     """Frame boundaries 0 = h_0 < .. < h_n = T of the time slabs the weight-gradient products are summed over."""
     import ctypes
     lib = _lib.load()
-    edges = (ctypes.c_int * 64)()
-    n = lib.pgasr_lstm_wgrad_slabs(int(T), ctypes.addressof(edges), 64)
+    n = lib.pgasr_lstm_wgrad_slabs(int(T), None, 0)          # the count alone
+    edges = (ctypes.c_int * (n + 1))()
+    lib.pgasr_lstm_wgrad_slabs(int(T), ctypes.addressof(edges), n + 1)
     return [int(edges[i]) for i in range(n + 1)]
 
 
@@ -801,6 +802,23 @@ def attention_ctx(dec, enc):
     ctx = torch.empty_like(dec)
     _lib.check(lib.pgasr_attention_ctx(_p(dec), _p(enc), NQ, B, T, H, _p(ctx), _stream()), "pgasr_attention_ctx")
     return ctx
+
+
+def lstm_cell(gh, xp, c, h, h_out=None):
+    """One step of the decoder's LSTM cell in place (include/pgasr_hip.h, pgasr_lstm_cell_f32): gh, xp (B,4H) contiguous,
+    c, h (B,H) updated, h_out (B,H) optional copy of the new h (the decoder's output row)."""
+    lib = _lib.load()
+    for n, t in (("gh", gh), ("xp", xp), ("c", c), ("h", h)):
+        _req(t, torch.float32, n)
+    B, H = c.shape
+    if gh.shape != (B, 4 * H) or xp.shape != (B, 4 * H) or h.shape != (B, H) or not (gh.is_contiguous() and xp.is_contiguous() and c.is_contiguous() and h.is_contiguous()):
+        raise _lib.PgasrError("lstm_cell: gh, xp (B,4H) and c, h (B,H), all contiguous")
+    if h_out is not None:
+        _req(h_out, torch.float32, "h_out")
+        if h_out.shape != (B, H) or not h_out.is_contiguous():
+            raise _lib.PgasrError("lstm_cell: h_out (B,H) contiguous")
+    _lib.check(lib.pgasr_lstm_cell_f32(_p(gh), _p(xp), _p(c), _p(h), _p(h_out), B, H, _stream()),
+               "pgasr_lstm_cell_f32")
 
 
 # ------------------------------------------------------------------------------------------

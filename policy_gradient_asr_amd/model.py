@@ -114,8 +114,8 @@ class Decoder(nn.Module):
     ``lstm.*_l0``; ``nn.LSTM`` is a parameter container here, never called: its cuDNN/MIOpen path is not used).
     DOCUMENTED DIVERGENCE (like ``Seq2Seq.forward``): the reference builds the list `preds`, prints the shape of its stack and returns
     None (model.py:112-117); this returns that stack, (L, B, 2 * hidden), and prints nothing.  Forward only.
-    The recurrent part is L dependent steps of (B,hidden) x (hidden,4 hidden) on the exact fp32 MFMA GEMM plus pointwise gates --
-    the BLSTM sweep kernels are built for H = 256 bidirectional layers and do not take this shape."""
+    The recurrent part is L dependent steps of (B,hidden) x (hidden,4 hidden) on the exact fp32 MFMA GEMM plus one cell kernel
+    (``pgasr_lstm_cell_f32``) -- the BLSTM sweep kernels are built for H = 256 bidirectional layers and do not take this shape."""
 
     def __init__(self, alphabet_size, hidden_size):
         super().__init__()
@@ -143,11 +143,7 @@ class Decoder(nn.Module):
         dec_out = torch.empty(L, B, H, dtype=torch.float32, device=w_ih.device)
         for t in range(L):
             hipops.gemm(h, w_hh, g, M=B, N=4 * H, K=H, transB=True, precision=0)
-            g += xp[t]
-            i, f, gg, o = torch.sigmoid(g[:, :H]), torch.sigmoid(g[:, H:2 * H]), torch.tanh(g[:, 2 * H:3 * H]), torch.sigmoid(g[:, 3 * H:])
-            c = f * c + i * gg
-            h = (o * torch.tanh(c)).contiguous()
-            dec_out[t] = h
+            hipops.lstm_cell(g, xp[t], c, h, dec_out[t])          # gates, c, h in one kernel (csrc/attention.hip)
         ctx = hipops.attention_ctx(dec_out, encoder_outputs.to(w_ih.device).contiguous())                       # (L,B,H): row q = t * B + b
         return torch.cat((dec_out, ctx), dim=2)
 

@@ -66,28 +66,30 @@ def test_workspace_query_needs_no_gpu(lib):
 def test_weight_gradient_time_slabs_need_no_gpu(lib):
     """pgasr_lstm_wgrad_slabs: the frame boundaries that DEFINE the summation order of a layer's weight-gradient products (and
     the publication points of a streamed backward sweep) are a host-side function of T alone: 0 = h_0 < .. < h_n = T, sizes
-    16, 24, 32, 48, 64, 88, 120, 168, 168, .. growing away from frame 0, the last slab at most 1.5 sizes."""
+    16, 24, 32, 40, 48, 64, 80, 104, 128, 128, .. growing away from frame 0 (x 5/4, cap 128: round 5, sized for the six-product kernel),
+    the last slab at most 1.5 sizes."""
     lib.pgasr_lstm_wgrad_slabs.restype = ctypes.c_int
     lib.pgasr_lstm_wgrads_workspace_bytes.restype = ctypes.c_size_t
-    buf = (ctypes.c_int * 64)()
+    buf = (ctypes.c_int * 128)()
 
     def edges(T):
-        n = lib.pgasr_lstm_wgrad_slabs(T, buf, 64)
+        n = lib.pgasr_lstm_wgrad_slabs(T, buf, 128)
+        assert lib.pgasr_lstm_wgrad_slabs(T, None, 0) == n       # the count alone
         return [buf[i] for i in range(n + 1)]
-    assert edges(1000) == [0, 16, 40, 72, 120, 184, 272, 392, 560, 728, 896, 1000]
+    assert edges(1000) == [0, 16, 40, 72, 112, 160, 224, 304, 408, 536, 664, 792, 920, 1000]
     assert edges(24) == [0, 24] and edges(25) == [0, 16, 25] and edges(1) == [0, 1]
-    assert lib.pgasr_lstm_wgrad_slabs(0, buf, 64) == 0
-    sizes = [16, 24, 32, 48, 64, 88, 120, 168]
+    assert lib.pgasr_lstm_wgrad_slabs(0, buf, 128) == 0
+    sizes = [16, 24, 32, 40, 48, 64, 80, 104, 128]
     for T in list(range(1, 400)) + [777, 1000, 1500, 4096, 8191]:
         e = edges(T)
-        assert e[0] == 0 and e[-1] == T and all(a < b for a, b in zip(e, e[1:])) and len(e) - 1 <= 63
+        assert e[0] == 0 and e[-1] == T and all(a < b for a, b in zip(e, e[1:])) and len(e) - 1 <= 72
         d = [b - a for a, b in zip(e, e[1:])]
-        want = [sizes[min(i, 7)] for i in range(len(d) - 1)]
+        want = [sizes[min(i, 8)] for i in range(len(d) - 1)]
         assert d[:-1] == want
-        nxt = sizes[min(len(d) - 1, 7)]
+        nxt = sizes[min(len(d) - 1, 8)]
         assert 0 < d[-1] <= nxt + nxt // 2
     # workspace of the two products: one partial slab set per time slab
-    assert lib.pgasr_lstm_wgrads_workspace_bytes(1000, 512) == 256 + 11 * (2048 * 512 + 2 * 1024 * 256) * 4
+    assert lib.pgasr_lstm_wgrads_workspace_bytes(1000, 512) == 256 + 13 * (2048 * 512 + 2 * 1024 * 256) * 4
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -4,7 +4,8 @@ The headline f32 train step with the sweeps' diagnostic switches (results invali
   flags 0x100  storer waves issue no bulk stores (gates / c / h / dgates rows never leave the CU)
   flags 0x200  loader waves issue no LDS-DMA (the staged rows are never read from the ring)
   flags 0x300  both
-Prints ms per step, the phases and the six sweeps for each variant.  PREC=f32|bf16x3, STEPS (default 30)."""
+Prints ms per step, the phases and the six sweeps for each variant.  PREC=f32|bf16x3, STEPS (default 30), NOWG=1: no weight-gradient
+products (their workgroups hold the CUs the next layer's feed wants at the start of its sweep: how much is that?)."""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -21,6 +22,8 @@ m = Seq2Seq(V, n_feats=F); m.apply(weights); m = m.to(dev).train()
 tr = PolicyGradientTrainer(m, lr=0.0, lam=1.0, seed=1234, precision=prec)     # lr 0: garbage gradients of the diagnostic variants change nothing
 batch = [v.to(dev) for v in synth_batch(100)]
 hipops.adam_step = lambda *a, **k: None       # the diagnostic variants produce garbage gradients: keep the parameters (all variants alike)
+if os.environ.get("NOWG"):                    # no weight-gradient products at all (results invalid): what do the fed sweeps cost without their competition?
+    hipops.lstm_wgrads = lambda *a, **k: None
 for flags in [int(f, 0) for f in os.environ.get("FLAGS", "0,0x100,0x200,0x300,0").split(",")]:
     hipops.LSTM_FLAGS = flags
     for i in range(4):
