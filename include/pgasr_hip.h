@@ -456,7 +456,7 @@ int pgasr_lstm_layer_bwd_streamed(float* gates, const float* out, const float* c
  *   descending sort (ties -> first insertion) follow the reference exactly; scores are fp64.
  *   flags bit 0: out_tokens / out_len are given AFTER collapse_fn (adjacent duplicate symbols removed,
  *   CTCdecoder.py:119-131) -- the string policy_grad.py:8 and model.py:326 score; bit 1: never take the
- *   single-wave kernel.  fp32 input with beam <= 16, V <= 32 and T * beam <= 24576 (the reward hypothesis inside
+ *   single-wave kernel.  fp32 input with beam <= 16, V <= 64 (8 symbols per lane up to 32, 16 beyond) and T * beam <= 24576 (the reward hypothesis inside
  *   the train step) runs as ONE WAVE per utterance with the prefix trie in LDS (no workspace traffic); the scores
  *   of the two fp32 kernels agree to ~1e-7 relative, their hypotheses wherever no two candidates are closer than that.
  * ---------------------------------------------------------------------------------------- */

@@ -14,6 +14,7 @@
 // Scores are fp64 (log-sum-exp exactly as CTCdecoder.py:31-39: max, sum of exps in argument order,
 // log); this is integer/latency work, not MFMA work.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -286,12 +287,14 @@ inline size_t beam_lds_bytes(int K, int V) {
 
 // =====================================================================================================================
 // Small-beam search for the training path (reward hypothesis of policy_grad.py:6-8 inside the train step):
-// fp32 device log-probs, beam <= 16, V <= 32, T * beam <= 24576 and T <= 4096.  ONE WAVE per utterance, no workgroup barrier, no
+// fp32 device log-probs, beam <= 16, V <= 64, T * beam <= 24576 and T <= 4096.  ONE WAVE per utterance, no workgroup barrier, no
 // LDS sort: the generic kernel above spends 24 us per frame in 45 LDS bitonic passes with barriers (24 ms for T = 1000);
 // a frame here is ~800 wave instructions.
 //
 //   lane = (q = lane / 16, j = lane % 16): entry j's state (p_b, p_nb, total, node id, last symbol, parent id) is
-//     replicated in the four 16-lane rows; lane (q, j) owns the candidates (entry j, symbol 8q + i), i < 8 -- the slot
+//     replicated in the four 16-lane rows; lane (q, j) owns the candidates (entry j, symbol SPL q + i), i < SPL = 8 (V <= 32; 16 for
+//     V <= 64, round 5: same kernel, twice the candidates per lane, a 63-exchange network; 4.5-4.9 ms for 32 x T = 1000 at beam 16 against
+//     3.2-4.1 at V <= 32 and 45 ms on the generic kernel, tools/dev/r5_beam_v64.py) -- the slot
 //     of the blank symbol holds entry j's "stay" candidate (prefix unchanged).
 //   scores: the same algebra as CTCdecoder.py:74-106 with the per-entry total lse(p_b, p_nb) factored out (an
 //     extension is total_j + log p(s), or p_b_j + log p(s) for a repeat of the last symbol; a stay collects blank,
@@ -315,15 +318,15 @@ __device__ unsigned long long beam_diag_counters[4];      // frames, frames redo
 #define PGASR_BEAM_UNROLL 1
 #endif
 namespace sb {
-constexpr int K_MAX = 16, V_MAX = 32, H = 32768, CH = 32;
+constexpr int K_MAX = 16, V_MAX = 64, H = 32768, CH = 32;     // template parameter SPL = symbols per lane: 8 (V <= 32) or 16 (V <= 64)
 constexpr long long MAX_NODES = 24576;               // T * beam: load factor of the table <= 0.75
 constexpr int MAX_TOKENS = 4096;                     // a hypothesis has at most T tokens and is staged in the 8 KB `frames` region (beam < 6 would admit longer T)
 constexpr unsigned ROOT = 0x8000u, NONE = 0xFFFFu, BAD_ID = 0x0FFFFFFFu;
 constexpr unsigned KEYMASK = 0x01FFFFFFu;
 constexpr size_t LDS_TABLE = (size_t)H * 4;          // 128 KB
-constexpr size_t LDS_FRAMES = (size_t)2 * CH * V_MAX * 4;
-constexpr size_t LDS_MM = 64;
-constexpr size_t LDS_BYTES = LDS_TABLE + LDS_FRAMES + LDS_MM;
+constexpr size_t lds_frames(int spl) { return (size_t)2 * CH * (4 * spl) * 4; }      // two chunks of CH frames, 4 * SPL symbols each
+constexpr size_t LDS_MM = 128;
+constexpr size_t lds_bytes(int spl) { return LDS_TABLE + lds_frames(spl) + LDS_MM; }
 
 __device__ __forceinline__ double lse2f(double a, double b) {
     // 1 + e^x with x <= 0 is in [1, 2]: the bare v_exp_f32 / v_log_f32 (base 2) need none of the library forms' range fix-ups
@@ -389,14 +392,20 @@ __device__ __forceinline__ unsigned wave_allmax(unsigned v) {
                       k[a] = ((unsigned long long)(sw_ ? yh_ : xh_) << 32) | (sw_ ? yl_ : xl_);                                    \
                       k[b] = ((unsigned long long)(sw_ ? xh_ : yh_) << 32) | (sw_ ? xl_ : yl_); }
 
+template <int SPL>
 __global__ __launch_bounds__(64) void beam_small_kernel(
     const float* __restrict__ lp, long long stride_t, long long stride_b, const int32_t* __restrict__ lengths,
     int T, int V, int K, int blank, int collapse, int32_t* __restrict__ out_tokens, int32_t* __restrict__ out_len,
     double* __restrict__ out_score) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* table = reinterpret_cast<unsigned*>(smem);
+    static_assert(SPL == 8 || SPL == 16, "8 or 16 symbols per lane");
+    constexpr int VM = 4 * SPL, SB = (SPL == 8) ? 3 : 4;                  // symbols the four rows cover; bits of a slot number
+    constexpr unsigned TKM = (unsigned)(VM << 5) - 1u;                     // largest first-touch rank (symbol << 5 | entry << 1 | bit)
+    constexpr int LOWBITS = 4 + SB + (SPL == 8 ? 10 : 11);                 // [rank | slot | entry] at the bottom of a key: 17 / 19 bits
+    using mask_t = typename std::conditional<SPL == 8, unsigned, unsigned long long>::type;      // one bit per symbol
     float* frames = reinterpret_cast<float*>(smem + LDS_TABLE);
-    unsigned* mm = reinterpret_cast<unsigned*>(smem + LDS_TABLE + LDS_FRAMES);
+    mask_t* mm = reinterpret_cast<mask_t*>(smem + LDS_TABLE + lds_frames(SPL));
     const int b = blockIdx.x, lane = threadIdx.x, q = lane >> 4, j = lane & 15;
     int Tb = lengths ? lengths[b] : T; Tb = Tb < 0 ? 0 : (Tb > T ? T : Tb);
 
@@ -413,18 +422,19 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
     int nb = 1, root_pos = 0;
 
     const float* base = lp + (long long)b * stride_b;
-    const int lsym = lane & 31, lhalf = lane >> 5;
-    float pre[16];
+    constexpr int FPI = 64 / VM, NPRE = CH / FPI;          // frames one wave instruction covers (2 / 1), instructions per chunk
+    const int lsym = lane & (VM - 1), lhalf = lane / VM;
+    float pre[NPRE];
     auto issue = [&](int t0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int t = t0 + 2 * i + lhalf;
+        for (int i = 0; i < NPRE; ++i) {
+            const int t = t0 + FPI * i + lhalf;
             pre[i] = (lsym < V && t < Tb) ? base[(long long)t * stride_t + lsym] : -INFINITY;
         }
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) frames[buf * (CH * V_MAX) + (2 * i + lhalf) * V_MAX + lsym] = pre[i];
+        for (int i = 0; i < NPRE; ++i) frames[buf * (CH * VM) + (FPI * i + lhalf) * VM + lsym] = pre[i];
     };
     issue(0); commit(0); issue(CH);
     __syncthreads();
@@ -437,9 +447,13 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
             issue(t + CH);
             __syncthreads();
         }
-        const float* fr = frames + ((t >> 5) & 1) * (CH * V_MAX) + (t & (CH - 1)) * V_MAX;
-        const float4 fa = *reinterpret_cast<const float4*>(fr + 8 * q), fc = *reinterpret_cast<const float4*>(fr + 8 * q + 4);
-        const float lpv[8] = {fa.x, fa.y, fa.z, fa.w, fc.x, fc.y, fc.z, fc.w};
+        const float* fr = frames + ((t >> 5) & 1) * (CH * VM) + (t & (CH - 1)) * VM;
+        float lpv[SPL];
+#pragma unroll
+        for (int c = 0; c < SPL / 4; ++c) {
+            const float4 f4 = *reinterpret_cast<const float4*>(fr + SPL * q + 4 * c);
+            lpv[4 * c] = f4.x; lpv[4 * c + 1] = f4.y; lpv[4 * c + 2] = f4.z; lpv[4 * c + 3] = f4.w;
+        }
         const float lp_bl = fr[blank];
         const float lp_la = fr[last >= 0 ? last : 0];
 
@@ -450,9 +464,9 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
             else if (par != NONE) pidx = (int)((table[par] >> 25) & 31u) - 1;
         }
         // DS operations of one wave execute in issue order: zero, atomic-or and read need no wait between them
-        if (lane < 16) mm[lane] = 0u;
-        if (lane < nb && pidx >= 0) atomicOr(&mm[pidx], 1u << last);
-        const unsigned mmask = __hip_atomic_load(&mm[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane < 16) mm[lane] = (mask_t)0;
+        if (lane < nb && pidx >= 0) atomicOr(&mm[pidx], (mask_t)1 << last);
+        const mask_t mmask = __hip_atomic_load(&mm[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 
         const int src = pidx >= 0 ? pidx : 0;
         const double pb_i = __shfl(pb, src, 16), tot_i = __shfl(tot, src, 16);
@@ -473,25 +487,26 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
         tie = tie < t_e ? tie : t_e;
         const double sstay = lse2f(npb, npnb);
 
-        // ---- the 8 candidates of this lane as keys ----
+        // ---- the SPL candidates of this lane as keys ----
         const long long tb0 = __double_as_longlong(tot);
         const double tot0 = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(tb0 >> 32), 0) << 32) |
                                                  (unsigned)__builtin_amdgcn_readlane((int)(unsigned)tb0, 0));
         const double ref = (tot0 == -INFINITY) ? 0.0 : tot0;
-        unsigned long long k[8];
+        unsigned long long k[SPL];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int s = 8 * q + i;
+        for (int i = 0; i < SPL; ++i) {
+            const int s = SPL * q + i;
             const bool is_bl = (s == blank);
-            const bool alive = (j < nb) && (s < V) && (is_bl || !((mmask >> s) & 1u));
+            const bool alive = (j < nb) && (s < V) && (is_bl || !((mmask >> s) & (mask_t)1));
             const double sx = ((s == last) ? pb : tot) + (double)lpv[i];
             const double sc = is_bl ? sstay : sx;
             const unsigned tk = is_bl ? tie : (((unsigned)s << 5) | ((unsigned)j << 1));
             const long long bits = __double_as_longlong(sc - ref);
             unsigned long long key = (unsigned long long)bits ^ ((unsigned long long)(bits >> 63) | 0x8000000000000000ull);
-            key = (key & ~0x1FFFFull) | ((unsigned long long)(0x3FFu - tk) << 7) | ((unsigned long long)i << 4) | (unsigned long long)j;
+            key = (key & ~((1ull << LOWBITS) - 1ull)) | ((unsigned long long)(TKM - tk) << (4 + SB)) | ((unsigned long long)i << 4) | (unsigned long long)j;
             k[i] = alive ? key : 0ull;
         }
+        if constexpr (SPL == 8) {
         // descending 8-input sorting network (19 exchanges)
         SB_CE(0, 1) SB_CE(2, 3) SB_CE(4, 5) SB_CE(6, 7)
         SB_CE(0, 2) SB_CE(1, 3) SB_CE(4, 6) SB_CE(5, 7)
@@ -500,6 +515,16 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
         SB_CE(1, 4) SB_CE(3, 6)
         SB_CE(2, 4) SB_CE(3, 5)
         SB_CE(3, 4)
+        } else {
+        // descending 16-input network: Batcher's odd-even merge sort, 63 exchanges in 10 layers (checked on all 2^16 0/1 inputs)
+        SB_CE(0, 1) SB_CE(2, 3) SB_CE(0, 2) SB_CE(1, 3) SB_CE(1, 2) SB_CE(4, 5) SB_CE(6, 7) SB_CE(4, 6) SB_CE(5, 7) SB_CE(5, 6)
+        SB_CE(0, 4) SB_CE(2, 6) SB_CE(2, 4) SB_CE(1, 5) SB_CE(3, 7) SB_CE(3, 5) SB_CE(1, 2) SB_CE(3, 4) SB_CE(5, 6)
+        SB_CE(8, 9) SB_CE(10, 11) SB_CE(8, 10) SB_CE(9, 11) SB_CE(9, 10) SB_CE(12, 13) SB_CE(14, 15) SB_CE(12, 14) SB_CE(13, 15) SB_CE(13, 14)
+        SB_CE(8, 12) SB_CE(10, 14) SB_CE(10, 12) SB_CE(9, 13) SB_CE(11, 15) SB_CE(11, 13) SB_CE(9, 10) SB_CE(11, 12) SB_CE(13, 14)
+        SB_CE(0, 8) SB_CE(4, 12) SB_CE(4, 8) SB_CE(2, 10) SB_CE(6, 14) SB_CE(6, 10) SB_CE(2, 4) SB_CE(6, 8) SB_CE(10, 12)
+        SB_CE(1, 9) SB_CE(5, 13) SB_CE(5, 9) SB_CE(3, 11) SB_CE(7, 15) SB_CE(7, 11) SB_CE(3, 5) SB_CE(7, 9) SB_CE(11, 13)
+        SB_CE(1, 2) SB_CE(3, 4) SB_CE(5, 6) SB_CE(7, 8) SB_CE(9, 10) SB_CE(11, 12) SB_CE(13, 14)
+        }
         // the lane's sorted list stays in registers; a pop shifts it (14 v_mov under a one-lane exec mask: no LDS round trip,
         // no wait on the K-round chain)
 
@@ -521,10 +546,10 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
         unsigned packed = 0u;
         int nnew = 0;
         {
-            unsigned hq[8];
-            unsigned perm = 0u;                    // slot of the d-th key of the sorted list, 3 bits each
+            unsigned hq[SPL];
+            unsigned perm[2] = {0u, 0u};           // slot of the d-th key of the sorted list, SB bits each, eight per word
 #pragma unroll
-            for (int d = 0; d < 8; ++d) { hq[d] = (unsigned)(k[d] >> 32); perm |= (((unsigned)k[d] >> 4) & 7u) << (3 * d); }
+            for (int d = 0; d < SPL; ++d) { hq[d] = (unsigned)(k[d] >> 32); perm[d >> 3] |= (((unsigned)k[d] >> 4) & (unsigned)(SPL - 1)) << (SB * (d & 7)); }
             unsigned won = 0u, wl_of = 0u;
             int pops = 0, rounds = 0;
             bool need_exact = tied_last;                        // straight to the exact rounds
@@ -545,8 +570,8 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
                     asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(wl_of) : "s"(wls), RC(r));                          \
                 }                                                                                                        \
                 won |= win ? (1u << (r)) : 0u;                                                                           \
-                _Pragma("unroll") for (int d = 0; d < 7; ++d) hq[d] = win ? hq[d + 1] : hq[d];                           \
-                hq[7] = win ? 0u : hq[7];                                                                                \
+                _Pragma("unroll") for (int d = 0; d < SPL - 1; ++d) hq[d] = win ? hq[d + 1] : hq[d];                     \
+                hq[SPL - 1] = win ? 0u : hq[SPL - 1];                                                                    \
             }
 #define SB_ROUND(r) if (K > (r)) SB_ROUND_BODY(r, "n")
             SB_ROUND(0) SB_ROUND(1) SB_ROUND(2) SB_ROUND(3) SB_ROUND(4) SB_ROUND(5) SB_ROUND(6) SB_ROUND(7)
@@ -567,8 +592,8 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
                 }
                 won |= win ? (1u << r) : 0u;
 #pragma unroll
-                for (int d = 0; d < 7; ++d) hq[d] = win ? hq[d + 1] : hq[d];
-                hq[7] = win ? 0u : hq[7];
+                for (int d = 0; d < SPL - 1; ++d) hq[d] = win ? hq[d + 1] : hq[d];
+                hq[SPL - 1] = win ? 0u : hq[SPL - 1];
             }
 #endif
                 need_exact = pops != rounds;
@@ -578,10 +603,14 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
                 nnew = rounds;
                 const unsigned wl = row0_to_all(wl_of);                       // lane (q, j): the winner lane of round j
                 const unsigned wwon = (unsigned)__shfl((int)won, (int)(wl & 63u), 64);
-                const unsigned wperm = (unsigned)__shfl((int)perm, (int)(wl & 63u), 64);
+                unsigned wperm = (unsigned)__shfl((int)perm[0], (int)(wl & 63u), 64);
                 const int idx = __popc(wwon & ((1u << j) - 1u));               // how many rounds before round j that lane had won
-                const unsigned slot = (wperm >> (3 * idx)) & 7u;
-                packed = ((wl >> 4) << 7) | (slot << 4) | (wl & 15u);
+                if constexpr (SPL == 16) {
+                    const unsigned wperm1 = (unsigned)__shfl((int)perm[1], (int)(wl & 63u), 64);
+                    wperm = (idx & 8) ? wperm1 : wperm;
+                }
+                const unsigned slot = (wperm >> (SB * (idx & 7))) & (unsigned)(SPL - 1);
+                packed = ((wl >> 4) << (4 + SB)) | (slot << 4) | (wl & 15u);
             } else {
 #ifdef PGASR_BEAM_DIAG
                 if (lane == 0) atomicAdd(&beam_diag_counters[1], 1ull);
@@ -601,12 +630,12 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
                     }
                     const int wl = __ffsll((long long)m) - 1;
                     const unsigned wlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)head, wl);
-                    const unsigned pk = ((unsigned)(wl >> 4) << 7) | (wlo & 0x7Fu);
+                    const unsigned pk = ((unsigned)(wl >> 4) << (4 + SB)) | (wlo & ((1u << (4 + SB)) - 1u));
                     if (j == r) packed = pk;
                     if (lane == wl) {
 #pragma unroll
-                        for (int d = 0; d < 7; ++d) k[d] = k[d + 1];
-                        k[7] = 0ull;
+                        for (int d = 0; d < SPL - 1; ++d) k[d] = k[d + 1];
+                        k[SPL - 1] = 0ull;
                     }
                     ++nnew;
                 }
@@ -617,8 +646,8 @@ __global__ __launch_bounds__(64) void beam_small_kernel(
         if (lane == 0) atomicAdd(&beam_diag_counters[0], 1ull);
 #endif
         // ---- the new beam: entry r <- winner r ----
-        const int pj = (int)(packed & 15u), slot = (int)((packed >> 4) & 7u), pq = (int)(packed >> 7);
-        const int s = 8 * pq + slot;
+        const int pj = (int)(packed & 15u), slot = (int)((packed >> 4) & (unsigned)(SPL - 1)), pq = (int)(packed >> (4 + SB));
+        const int s = SPL * pq + slot;
         const bool valid = j < nnew;
         const bool stay = (s == blank);
         const double g_tot = __shfl(tot, pj, 16), g_pb = __shfl(pb, pj, 16);
@@ -746,9 +775,12 @@ extern "C" int pgasr_ctc_beam_search(const void* log_probs, int is_f64, long lon
     const int collapse = flags & 1;
 #endif
     if (!is_f64 && !(flags & 2) && beam <= sb::K_MAX && V <= sb::V_MAX && (long long)T * beam <= sb::MAX_NODES && T <= sb::MAX_TOKENS) {
-        // training path: one wave per utterance, trie and candidate lists in LDS, no workspace traffic
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sb::beam_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb::LDS_BYTES);
-        PGASR_LAUNCH_KERNEL(sb::beam_small_kernel, dim3(B), dim3(64), sb::LDS_BYTES, st, (const float*)log_probs, stride_t, stride_b,
+        // training path: one wave per utterance, trie and candidate lists in LDS, no workspace traffic; 8 symbols per lane up to V = 32
+        // (the English alphabet of the headline), 16 up to V = 64 (round 5: CommonVoice's larger alphabets stay on this kernel)
+        auto kern = V <= 32 ? &sb::beam_small_kernel<8> : &sb::beam_small_kernel<16>;
+        const size_t lds_small = sb::lds_bytes(V <= 32 ? 8 : 16);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
+        PGASR_LAUNCH_KERNEL(kern, dim3(B), dim3(64), lds_small, st, (const float*)log_probs, stride_t, stride_b,
                            lengths, T, V, beam, blank, collapse, out_tokens, out_len, out_score);
         PGASR_CHECK_LAUNCH();
         return PGASR_OK;

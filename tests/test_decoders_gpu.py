@@ -58,9 +58,11 @@ def test_beam_batch_fp32_vs_oracle_and_lengths():
 
 @pytest.mark.parametrize("T,B,V,beam,blank", [(1, 3, 29, 16, 0), (8, 4, 29, 5, 0), (50, 6, 29, 16, 0), (200, 5, 29, 16, 0),
                                                (200, 3, 29, 1, 0), (60, 4, 4, 16, 0), (40, 4, 32, 16, 0), (90, 4, 29, 16, 3),
-                                               (300, 2, 29, 7, 0)])
+                                               (300, 2, 29, 7, 0),
+                                               # round 5: 16 symbols per lane for alphabets of 33 .. 64 symbols (CommonVoice beyond English)
+                                               (50, 4, 33, 16, 0), (120, 4, 48, 16, 0), (80, 3, 64, 16, 63), (200, 3, 40, 5, 0), (8, 2, 64, 1, 0)])
 def test_small_beam_kernel_vs_oracle_and_generic(T, B, V, beam, blank):
-    """The single-wave training-path search (fp32, beam <= 16, V <= 32) against the fp64 oracle on the SAME fp32
+    """The single-wave training-path search (fp32, beam <= 16, V <= 64: 8 symbols per lane up to V = 32, 16 beyond) against the fp64 oracle on the SAME fp32
     log-probs (hypothesis bit-exact, score 1e-6) and against the generic LDS-sort kernel; ragged lengths, peaked and
     flat frames, exact zeros (log p = -inf), fewer candidates than the beam (V = 4), a non-zero blank."""
     from policy_gradient_asr_amd import hipops
