@@ -437,6 +437,13 @@ def test_pg_step_with_beam_reward_vs_oracle():
     _pg_step_vs_oracle(4, 80, 120, 29, 12, [120, 90, 120, 64], [12, 9, 12, 5], seed=21, beam=16)
 
 
+def test_pg_step_with_beam_reward_and_a_forty_symbol_alphabet_vs_oracle():
+    """Round 5: an alphabet of 33 .. 64 symbols (CommonVoice beyond English; the reference reads its alphabet from a file, model.py:194-197)
+    keeps the single-wave beam kernel for the reward hypothesis (16 symbols per lane) -- the head takes the unfused GEMM + log-softmax
+    kernels (the fused head is V <= 32), everything else as above."""
+    _pg_step_vs_oracle(4, 80, 120, 40, 12, [120, 90, 120, 64], [12, 9, 12, 5], seed=22, beam=16)
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
 def test_pg_step_full_size_lambda1_vs_oracle(mode):
     """configs[2] as a whole step at the headline shape (B=32,T=1000,F=80,V=29,L=100), lambda = 1, in BOTH precision modes
