@@ -39,6 +39,9 @@ __device__ long long x6_stamp_out[8][16];
 #endif
 
 namespace {
+#ifdef PGASR_LSTM_DIAG
+__device__ unsigned x6_feed_diag[4096];      // [0] wall clock at workgroup 0's start, [16 + dir * mt + row tile] when that row tile was counted (the LAST feed that ran)
+#endif
 namespace x6c {
 constexpr int TM = 256, TN = 256, TK = 16, THREADS = 512;
 constexpr int NW = 4;                            // W stages in LDS: the DMA runs three steps ahead
@@ -145,6 +148,9 @@ __device__ __forceinline__ void mfma6(f32x16 (&acc)[2], const u32x4_t (&a)[3], c
 template <bool FEED, int VAR>
 __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];   // the ONLY LDS object
+#ifdef PGASR_LSTM_DIAG
+    if (FEED && threadIdx.x == 0 && blockIdx.x == 0) x6_feed_diag[0] = (unsigned)wall_clock64();     // workgroup 0's start (of the LAST feed that ran)
+#endif
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;      // (w made wave-uniform for the compiler -- readfirstlane -- spills: measured, not kept)
     const int wm = w >> 2, wn = w & 3;
     const int nk = g.K / TK;
@@ -159,23 +165,36 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   for (;;) {
     int tbx, tby;
-    int kt0 = 0, kt1 = nk, qpart = -1;      // step range of this work item; qpart >= 0: one quarter of a split tile
-    unsigned tile = 0;
+    int kt0 = 0, kt1 = nk, qpart = -1;      // step range of this work item; qpart >= 0: part qpart of a tile split into `parts` K ranges
+    unsigned tile = 0, parts = 1u, slab0 = 0u;     // slab0: the tile's first parked accumulator set
+#ifdef PGASR_LSTM_DIAG
+    unsigned diag_t_ = 0xFFFFFFFFu;
+#endif
     if (FEED) {
         unsigned* mailbox = reinterpret_cast<unsigned*>(smem + LDS_BYTES);
-        const unsigned S = (unsigned)g.split_tiles, ntot = (unsigned)g.mt_count * (unsigned)g.nt_count;
+        // queue order: S8 tiles in eighths, S tiles in quarters, S2 tiles in halves, the rest whole (round 5: the graded head -- see the host side)
+        const unsigned S8 = (unsigned)g.split8_tiles, S = (unsigned)g.split_tiles, S2 = (unsigned)g.split2_tiles, ntot = (unsigned)g.mt_count * (unsigned)g.nt_count;
+        const unsigned n8 = 8u * S8, n4 = 4u * S, n2 = 2u * S2;
         if (tid == 0) {
             // a head-only workgroup looks before it draws: past the head it leaves without taking an item (a late look may still draw one
             // whole tile: harmless)
-            if (head_only && __hip_atomic_load(g.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 4u * S) *mailbox = 0xFFFFFFFFu;
+            if (head_only && __hip_atomic_load(g.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n8 + n4) *mailbox = 0xFFFFFFFFu;
             else *mailbox = __hip_atomic_fetch_add(g.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         const unsigned t = *mailbox;
         __syncthreads();
-        if (t >= ntot + 3u * S) return;             // 4 S quarter items, then the remaining ntot - S whole tiles
-        if (t < 4u * S) { tile = t >> 2; qpart = (int)(t & 3u); kt0 = qpart * (nk >> 2); kt1 = kt0 + (nk >> 2); }
-        else tile = t - 3u * S;
+        if (t >= ntot + 7u * S8 + 3u * S + S2) return;             // 8 S8 + 4 S + 2 S2 part items, then the remaining whole tiles
+#ifdef PGASR_LSTM_DIAG
+        if (tid == 0 && t < 4u) x6_feed_diag[4 + t] = (unsigned)wall_clock64();          // the first four items: drawn at ..
+        if (tid == 0 && t >= n8 + n4 + n2 && t < n8 + n4 + n2 + 4u) x6_feed_diag[1024 + (t - n8 - n4 - n2)] = (unsigned)wall_clock64();      // .. and the first four whole tiles
+        diag_t_ = t;
+#endif
+        if (t < n8) { tile = t >> 3; qpart = (int)(t & 7u); parts = 8u; slab0 = 8u * tile; }
+        else if (t < n8 + n4) { const unsigned u = t - n8; tile = S8 + (u >> 2); qpart = (int)(u & 3u); parts = 4u; slab0 = n8 + 4u * (u >> 2); }
+        else if (t < n8 + n4 + n2) { const unsigned u = t - n8 - n4; tile = S8 + S + (u >> 1); qpart = (int)(u & 1u); parts = 2u; slab0 = n8 + n4 + 2u * (u >> 1); }
+        else tile = t - 7u * S8 - 3u * S - S2;
+        if (qpart >= 0) { kt0 = qpart * (nk / (int)parts); kt1 = kt0 + nk / (int)parts; }
         const int half = g.nt_count >> 1, grp = (int)(tile / (unsigned)g.nt_count), j = (int)(tile % (unsigned)g.nt_count);
         tbx = j;
         tby = ((j < half) != (g.order != 0)) ? grp : g.mt_count - 1 - grp;
@@ -453,42 +472,48 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
     X6STAMP_FLUSH();
 
     if (FEED && qpart >= 0) {
-        // one quarter of a split tile: park the accumulators (thread-major: a wave instruction stores 256 contiguous
-        // bytes) write-through, count the arrival; the LAST of the four sums the quarters in index order and goes on to
-        // the epilogue, the others take their next work item
-        __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(g.slabs, 0, (int)(unsigned)((size_t)g.split_tiles * 4 * SLAB_FLOATS * 4), 0x00020000);
-        const unsigned sbq = (tile * 4u + (unsigned)qpart) * 128u;
+        // one part of a split tile: park the accumulators write-through, count the arrival; the LAST of the tile's parts sums them in index
+        // order and goes on to the epilogue, the others take their next work item.  Slab layout [32 vectors][512 threads][4 floats]: a wave
+        // instruction moves 1 KB of consecutive bytes (round 5: with 4-byte accesses -- 256 B per instruction -- the last arriver of the FIRST
+        // tile needed 56 us for its sum and epilogue, tools/dev/r5_feed_timeline.py: parked at 72 us, counted at 128)
+        __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(g.slabs, 0, (int)(unsigned)((size_t)g.slab_count * SLAB_FLOATS * 4), 0x00020000);
+        const unsigned sbq = (slab0 + (unsigned)qpart) * 32u;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), srs, ((sbq + (unsigned)((i * 2 + j) * 16 + r)) * 512u + (unsigned)tid) * 4u, 0, 16);
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const u32x4_t v4 = {__float_as_uint(acc[i][j][4 * r4]), __float_as_uint(acc[i][j][4 * r4 + 1]),
+                                        __float_as_uint(acc[i][j][4 * r4 + 2]), __float_as_uint(acc[i][j][4 * r4 + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(v4, srs, ((sbq + (unsigned)((i * 2 + j) * 4 + r4)) * 512u + (unsigned)tid) * 16u, 0, 16);
+                }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         unsigned* mailbox = reinterpret_cast<unsigned*>(smem + LDS_BYTES);
         if (tid == 0) *mailbox = __hip_atomic_fetch_add(g.arrive + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef PGASR_LSTM_DIAG
+        if (tid == 0 && diag_t_ < 4u) x6_feed_diag[8 + diag_t_] = (unsigned)wall_clock64();      // .. parked at
+#endif
         __syncthreads();
         const unsigned before = *mailbox;
         __syncthreads();
-        if (before != 3u) continue;
-        // total = ((q0 + q1) + q2) + q3, whoever arrives last
+        if (before != parts - 1u) continue;
+        // total = ((p0 + p1) + p2) + .., whoever arrives last
+        for (unsigned qq = 0; qq < parts; ++qq) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float t = 0.f;
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) {
-                        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                            srs, (((tile * 4u + (unsigned)qq) * 128u + (unsigned)((i * 2 + j) * 16 + r)) * 512u + (unsigned)tid) * 4u, 0, 16));
-                        t = qq == 0 ? v : t + v;
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const u32x4_t v4 = __builtin_amdgcn_raw_buffer_load_b128(srs, (((slab0 + qq) * 32u + (unsigned)((i * 2 + j) * 4 + r4)) * 512u + (unsigned)tid) * 16u, 0, 16);
+                        acc[i][j][4 * r4]     = qq == 0 ? __uint_as_float(v4.x) : acc[i][j][4 * r4]     + __uint_as_float(v4.x);
+                        acc[i][j][4 * r4 + 1] = qq == 0 ? __uint_as_float(v4.y) : acc[i][j][4 * r4 + 1] + __uint_as_float(v4.y);
+                        acc[i][j][4 * r4 + 2] = qq == 0 ? __uint_as_float(v4.z) : acc[i][j][4 * r4 + 2] + __uint_as_float(v4.z);
+                        acc[i][j][4 * r4 + 3] = qq == 0 ? __uint_as_float(v4.w) : acc[i][j][4 * r4 + 3] + __uint_as_float(v4.w);
                     }
-                    acc[i][j][r] = t;
-                }
+        }
     }
 
     // epilogue (branch-free): 32x32 accumulator layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -530,6 +555,16 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
     __syncthreads();
     if (tid == 0)
         __hip_atomic_fetch_add(g.tiles_done + (tbx < (g.nt_count >> 1) ? 0 : g.mt_count) + tby, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef PGASR_LSTM_DIAG
+    {
+        const unsigned nh_ = 8u * (unsigned)g.split8_tiles + 4u * (unsigned)g.split_tiles + 2u * (unsigned)g.split2_tiles;
+        if (tid == 0 && diag_t_ >= nh_ && diag_t_ < nh_ + 4u) x6_feed_diag[1028 + (diag_t_ - nh_)] = (unsigned)wall_clock64();
+    }
+    if (tid == 0) {      // when was which row tile counted (100 MHz wall clock; the LAST feed that ran): tools/dev/r5_feed_timeline.py
+        const unsigned slot_ = 16u + (unsigned)((tbx < (g.nt_count >> 1) ? 0 : g.mt_count) + tby);
+        if (slot_ < 4096u) x6_feed_diag[slot_] = (unsigned)wall_clock64();
+    }
+#endif
   }
 }
 }  // namespace x6c
@@ -819,12 +854,29 @@ __global__ __launch_bounds__(256) void pack_x6w_kernel(const float* __restrict__
 // Round 5, tools/dev/r5_head_help.sh, A/B/A/B on one box: fed backward sweeps 1.64-1.66 -> 1.61-1.63 ms, f32 step 10.05-10.10 -> 10.02 ms.  Small,
 // because the stall only moves: the tiles behind the head still wait for the free XCDs' CUs (NOTES 0.2).
 constexpr int X6_HEAD_HELP_DEFAULT = 1;
+// Tile groups (of nt tiles, in the order the sweep takes them) in K-eighths, -quarters and -halves at the head of a feed.  Round 5, one box,
+// f32 step (tools/dev/r5_graded_head.sh: eighths, quarters, halves -> ms): 0,16,0 9.78 / 9.79; 0,16,16 9.745; 0,16,32 9.78; 2,14,16 9.82; 2,14,32 9.76;
+// 4,12,32 9.78.  The halves take the sweep's second stall away (group 16 used to be ready ~150 us after the sweep wanted it) and the 16-byte slab
+// accesses 43 us of its first -- and the fed sweeps gain only 0.02 ms of the 0.09, because what sets their pace inside the step is the CLOCK: 2.40 GHz
+// with no GEMM beside them, 2.2-2.3 with the weight-gradient and feed GEMMs on the other XCDs, 2.14-2.2 when the head keeps more of them busy
+// (in-kernel shader clock against the 100 MHz wall clock, tools/dev/r5_feed_timeline.py; 3,220 cycles per step in every case).
+constexpr int X6_SPLIT8_GROUPS_DEFAULT = 0, X6_SPLIT4_GROUPS_DEFAULT = 16, X6_SPLIT2_GROUPS_DEFAULT = 16;
 constexpr int X6_FEED_SPLIT_MAX = 128;     // split tiles per feed at most: 4 x 128 slabs of 256 KB = 128 MB of workspace (arrival counters: words 64..191 of the head)
 // Time-ordered tile groups (of nt tiles) at the head of a feed whose tiles are split into K-quarters (PGASR_X6_SPLIT_GROUPS, read at every
 // call; the fed and the sequential order read the same value, so they keep giving the same bits).
 int x6_split_groups() {
     const char* e = getenv("PGASR_X6_SPLIT_GROUPS");
-    const int v = e ? atoi(e) : 16;
+    const int v = e ? atoi(e) : X6_SPLIT4_GROUPS_DEFAULT;
+    return v < 0 ? 0 : v;
+}
+int x6_split8_groups() {      // tile groups in K-eighths in front of the quarters
+    const char* e = getenv("PGASR_X6_SPLIT8_GROUPS");
+    const int v = e ? atoi(e) : X6_SPLIT8_GROUPS_DEFAULT;
+    return v < 0 ? 0 : v;
+}
+int x6_split2_groups() {      // tile groups in K-halves behind the quarters
+    const char* e = getenv("PGASR_X6_SPLIT2_GROUPS");
+    const int v = e ? atoi(e) : X6_SPLIT2_GROUPS_DEFAULT;
     return v < 0 ? 0 : v;
 }
 // K in quarters for the first tiles of a feed (K >= 1024: the input-gradient feeds).  The K = 512 projections in quarters were measured
@@ -922,19 +974,31 @@ extern "C" int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int 
     // the first tile groups (16 time-ordered groups, at most X6_FEED_SPLIT_MAX tiles and what the workspace holds) are split into
     // K-quarters: the sweep is waiting for exactly these
     const int quarters = x6_quarters(K);
-    int split = 0;
+    int split8 = 0, split = 0, split2 = 0;
     if (quarters == 4) {
-        const size_t room = (workspace_bytes - 1024) / ((size_t)4 * x6c::SLAB_FLOATS * 4);
-        split = x6_split_groups() * nt;
-        if (split > X6_FEED_SPLIT_MAX) split = X6_FEED_SPLIT_MAX;
-        if ((size_t)split > room) split = (int)room;
-        if (split > mt * nt) split = mt * nt;
+        // THE GRADED HEAD (round 5, tools/dev/r5_feed_timeline.py): a whole tile of the input-gradient product (K = 2048) is 260-275 us on one CU and
+        // the sweep takes a tile group every ~11 us, so what the sweep waits for is not only its first rows: with sixteen groups in quarters and whole
+        // tiles behind them, group 16 was ready at ~340 us where the sweep wanted it at ~190 -- its second stall (20-40 us per cluster after the
+        // 120 us at step 0).  Groups in eighths first (PGASR_X6_SPLIT8_GROUPS), then quarters (PGASR_X6_SPLIT_GROUPS), then halves
+        // (PGASR_X6_SPLIT2_GROUPS), then whole tiles; every tile is the fixed-order sum of its parts, its position decides how many: the fed and the
+        // sequential order run the same decomposition and give the same bits.
+        const size_t room = (workspace_bytes - 1024) / ((size_t)x6c::SLAB_FLOATS * 4);          // parked accumulator sets
+        const int total = mt * nt;
+        split8 = x6_split8_groups() * nt; split = x6_split_groups() * nt; split2 = x6_split2_groups() * nt;
+        if (K % (8 * x6c::TK) || K < 32 * x6c::TK) { split += split8; split8 = 0; }
+        if (split8 > total) split8 = total;
+        if (split8 + split > total) split = total - split8;
+        if (split8 + split + split2 > total) split2 = total - split8 - split;
+        while (split8 + split + split2 > X6_FEED_SPLIT_MAX || (size_t)(8 * split8 + 4 * split + 2 * split2) > room) {     // arrival words; slabs
+            if (split2 > 0) --split2; else if (split > 0) --split; else --split8;
+        }
     }
     DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, nullptr, 0.f, (unsigned*)workspace, xcc_busy, tiles_done, mt, nt, order,
                   quarters, split, (float*)((char*)workspace + 1024), (unsigned*)workspace + 64, 0, Wmid};
+    g.split8_tiles = split8; g.split2_tiles = split2; g.slab_count = 8 * split8 + 4 * split + 2 * split2;
     {   // PGASR_X6_HEAD_HELP (read at every call; a speed hint, the same bits either way): workgroups on the sweep's XCDs take K-split head items
         const char* eh = getenv("PGASR_X6_HEAD_HELP");
-        g.head_help = (eh ? atoi(eh) : X6_HEAD_HELP_DEFAULT) != 0 && split > 0;
+        g.head_help = (eh ? atoi(eh) : X6_HEAD_HELP_DEFAULT) != 0 && split8 + split > 0;
     }
     for (int pass = 0; pass < 2; ++pass) {     // one persistent workgroup per CU; pass 1 ignores the busy counters
         if (pass == 1) g.xcc_busy = nullptr;
@@ -984,3 +1048,11 @@ int pgasr_internal_tn6_launch(PgasrTn256Args a, int masked_then_unmasked, hipStr
     }
     return PGASR_OK;
 }
+
+#ifdef PGASR_LSTM_DIAG
+extern "C" int pgasr_diag_x6_feed(unsigned* out, int reset) {      // host copy of x6_feed_diag
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(x6_feed_diag), sizeof(unsigned) * 4096) != hipSuccess) return 1;
+    if (reset) { static unsigned z[4096]; if (hipMemcpyToSymbol(HIP_SYMBOL(x6_feed_diag), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif

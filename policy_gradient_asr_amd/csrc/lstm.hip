@@ -139,10 +139,18 @@ struct LstmArgs {
 // Diagnostic build (-DPGASR_LSTM_DIAG): what the loader wave's wait for the staging ring costs.  Per cluster, hello words 48..51 (member 5)
 // and 52..55 (member 0): waits whose first poll found the slot not ready, retries in total, cycles spent in ring_wait, steps.
 #ifdef PGASR_LSTM_DIAG
+// .. and WHERE in the sweep member 0's loader waited (round 5, tools/dev/r5_feed_timeline.py): per cluster the first 16 late steps as
+// (step, cycles / 16, 100 MHz wall clock at the end of the wait), word 60 = wall clock when the loader first asked for a step
+__device__ unsigned lstm_diag_late[8][64];
 #define RW_DECL unsigned rw_late_ = 0, rw_retry_ = 0, rw_steps_ = 0; long long rw_cyc_ = 0, rw_t0_ = 0; bool rw_first_ = true
-#define RW_BEGIN() do { rw_t0_ = clock64(); rw_first_ = true; ++rw_steps_; } while (0)
+#define RW_BEGIN() do { rw_t0_ = clock64(); rw_first_ = true; if (rw_steps_ == 0 && g == 0) lstm_diag_late[cl & 7][60] = (unsigned)wall_clock64();   \
+                        if (g == 0 && (s & 127) == 0 && (s >> 7) < 8) { lstm_diag_late[cl & 7][48 + (s >> 7)] = (unsigned)wall_clock64();    /* the loader's request for steps 0, 128, .., 896 */ \
+                                                                        lstm_diag_late[cl & 7][56 - 16 + (s >> 7)] = (unsigned)clock64(); }    /* .. and the shader clock's count there (words 40..47) */ \
+                        ++rw_steps_; } while (0)
 #define RW_RETRY() do { if (rw_first_) { ++rw_late_; rw_first_ = false; } ++rw_retry_; } while (0)
-#define RW_END() do { rw_cyc_ += clock64() - rw_t0_; } while (0)
+#define RW_END() do { const long long d_ = clock64() - rw_t0_; rw_cyc_ += d_;                                                   \
+                      if (!rw_first_ && g == 0 && rw_late_ <= 16) { unsigned* o_ = &lstm_diag_late[cl & 7][3 * (rw_late_ - 1)];  \
+                          o_[0] = (unsigned)s; o_[1] = (unsigned)(d_ >> 4); o_[2] = (unsigned)wall_clock64(); } } while (0)
 #define RW_FLUSH() do { if (w == LOADER_WAVE && lane == 0 && (g == 5 || g == 0)) { unsigned* o_ = a.hello + (size_t)cl * HELLO_STRIDE + (g == 5 ? 48 : 52); \
                         o_[0] = rw_late_; o_[1] = rw_retry_; o_[2] = (unsigned)(rw_cyc_ >> 4); o_[3] = rw_steps_; } } while (0)
 #else
@@ -1626,3 +1634,11 @@ extern "C" int pgasr_stream_gate_report(const unsigned* words, int count, int ne
     PGASR_CHECK_LAUNCH();
     return PGASR_OK;
 }
+
+#ifdef PGASR_LSTM_DIAG
+extern "C" int pgasr_diag_lstm_late(unsigned* out, int reset) {      // host copy of lstm_diag_late [8 clusters][64 words] (the LAST sweep that ran)
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lstm_diag_late), sizeof(unsigned) * 8 * 64) != hipSuccess) return 1;
+    if (reset) { static unsigned z[8 * 64]; if (hipMemcpyToSymbol(HIP_SYMBOL(lstm_diag_late), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif

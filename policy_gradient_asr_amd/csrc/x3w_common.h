@@ -28,6 +28,8 @@ struct DmaGemmArgs {
     int single;                 // FEED: every workgroup takes ONE work item and leaves (the head launch in front of a sweep)
     const unsigned short* Wmid; // six-product kernels (gemm_x6.hip): the middle plane of the 3-plane split (hi, mid, lo)
     int head_help;              // six-product FEED: workgroups on the sweep's own XCDs take K-split head items before they leave (0: they leave at once)
+    int split8_tiles, split2_tiles;   // six-product FEED: tiles in K-eighths in front of the split_tiles quarter tiles, tiles in K-halves behind them
+    int slab_count;             // six-product FEED: parked accumulator sets in `slabs` (8 split8 + 4 split + 2 split2)
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_base) {
