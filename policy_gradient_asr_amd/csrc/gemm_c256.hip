@@ -298,18 +298,22 @@ __global__ __launch_bounds__(THREADS) void gemm_x3c_kernel(DmaGemmArgs g) {
     asm volatile("" : "+v"(araw[NA - 1][0]), "+v"(araw[NA - 1][1]), "+v"(araw[NA - 1][2]), "+v"(araw[NA - 1][3]));
 
     if (FEED && qpart >= 0) {
-        // one quarter of a split tile: park the accumulators (thread-major: a wave instruction stores 256 contiguous
-        // bytes) write-through, count the arrival; the LAST of the four sums the quarters in index order and goes on to
-        // the epilogue, the others take their next work item
+        // one quarter of a split tile: park the accumulators write-through, count the arrival; the LAST of the four sums the quarters in
+        // index order and goes on to the epilogue, the others take their next work item.  Slab layout [32 vectors][512 threads][4 floats]: a
+        // wave instruction moves 1 KB of consecutive bytes (round 5, measured on the six-product kernel: with 4-byte accesses the last arriver
+        // of a feed's FIRST tile needed 56 us for its sum and epilogue -- parked at 72 us, counted at 128; gemm_x6.hip)
         __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(g.slabs, 0, (int)(unsigned)((size_t)g.split_tiles * 4 * SLAB_FLOATS * 4), 0x00020000);
-        const unsigned sbq = (tile * 4u + (unsigned)qpart) * 128u;
+        const unsigned sbq = (tile * 4u + (unsigned)qpart) * 32u;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), srs, ((sbq + (unsigned)((i * 2 + j) * 16 + r)) * 512u + (unsigned)tid) * 4u, 0, 16);
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const u32x4_t v4 = {__float_as_uint(acc[i][j][4 * r4]), __float_as_uint(acc[i][j][4 * r4 + 1]),
+                                        __float_as_uint(acc[i][j][4 * r4 + 2]), __float_as_uint(acc[i][j][4 * r4 + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(v4, srs, ((sbq + (unsigned)((i * 2 + j) * 4 + r4)) * 512u + (unsigned)tid) * 16u, 0, 16);
+                }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         unsigned* mailbox = reinterpret_cast<unsigned*>(smem + LDS_BYTES);
@@ -319,21 +323,20 @@ __global__ __launch_bounds__(THREADS) void gemm_x3c_kernel(DmaGemmArgs g) {
         __syncthreads();
         if (before != 3u) continue;
         // total = ((q0 + q1) + q2) + q3, whoever arrives last
+        for (unsigned qq = 0; qq < 4u; ++qq) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float t = 0.f;
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) {
-                        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                            srs, (((tile * 4u + (unsigned)qq) * 128u + (unsigned)((i * 2 + j) * 16 + r)) * 512u + (unsigned)tid) * 4u, 0, 16));
-                        t = qq == 0 ? v : t + v;
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const u32x4_t v4 = __builtin_amdgcn_raw_buffer_load_b128(srs, (((tile * 4u + qq) * 32u + (unsigned)((i * 2 + j) * 4 + r4)) * 512u + (unsigned)tid) * 16u, 0, 16);
+                        acc[i][j][4 * r4]     = qq == 0 ? __uint_as_float(v4.x) : acc[i][j][4 * r4]     + __uint_as_float(v4.x);
+                        acc[i][j][4 * r4 + 1] = qq == 0 ? __uint_as_float(v4.y) : acc[i][j][4 * r4 + 1] + __uint_as_float(v4.y);
+                        acc[i][j][4 * r4 + 2] = qq == 0 ? __uint_as_float(v4.z) : acc[i][j][4 * r4 + 2] + __uint_as_float(v4.z);
+                        acc[i][j][4 * r4 + 3] = qq == 0 ? __uint_as_float(v4.w) : acc[i][j][4 * r4 + 3] + __uint_as_float(v4.w);
                     }
-                    acc[i][j][r] = t;
-                }
+        }
     }
 
     // epilogue (branch-free): 32x32 accumulator layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

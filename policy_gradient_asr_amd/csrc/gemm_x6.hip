@@ -861,6 +861,7 @@ constexpr int X6_HEAD_HELP_DEFAULT = 1;
 // with no GEMM beside them, 2.2-2.3 with the weight-gradient and feed GEMMs on the other XCDs, 2.14-2.2 when the head keeps more of them busy
 // (in-kernel shader clock against the 100 MHz wall clock, tools/dev/r5_feed_timeline.py; 3,220 cycles per step in every case).
 constexpr int X6_SPLIT8_GROUPS_DEFAULT = 0, X6_SPLIT4_GROUPS_DEFAULT = 16, X6_SPLIT2_GROUPS_DEFAULT = 16;
+constexpr int X6_FWD_SPLIT4_GROUPS_DEFAULT = 2;      // r5_fwd_quarters2.sh, one box: 0 groups 9.72-9.74 ms, 2: 9.67, 4: 9.68-9.70, 8: 9.73, 16: 9.71
 constexpr int X6_FEED_SPLIT_MAX = 128;     // split tiles per feed at most: 4 x 128 slabs of 256 KB = 128 MB of workspace (arrival counters: words 64..191 of the head)
 // Time-ordered tile groups (of nt tiles) at the head of a feed whose tiles are split into K-quarters (PGASR_X6_SPLIT_GROUPS, read at every
 // call; the fed and the sequential order read the same value, so they keep giving the same bits).
@@ -874,19 +875,25 @@ int x6_split8_groups() {      // tile groups in K-eighths in front of the quarte
     const int v = e ? atoi(e) : X6_SPLIT8_GROUPS_DEFAULT;
     return v < 0 ? 0 : v;
 }
+int x6_fwd_split_groups() {   // K < 1024 (the forward projections): tile groups in quarters; no eighths, no halves
+    const char* e = getenv("PGASR_X6_FWD_SPLIT_GROUPS");
+    const int v = e ? atoi(e) : X6_FWD_SPLIT4_GROUPS_DEFAULT;
+    return v < 0 ? 0 : v;
+}
 int x6_split2_groups() {      // tile groups in K-halves behind the quarters
     const char* e = getenv("PGASR_X6_SPLIT2_GROUPS");
     const int v = e ? atoi(e) : X6_SPLIT2_GROUPS_DEFAULT;
     return v < 0 ? 0 : v;
 }
-// K in quarters for the first tiles of a feed (K >= 1024: the input-gradient feeds).  The K = 512 projections in quarters were measured
-// (round 4, PGASR_X6_QUARTER_K=512, same box, 2 x 40 steps each): forward sweeps 1.54 against 1.47 ms, step 10.67-10.70 against
-// 10.45-10.53 -- four items, a parked accumulator set and a reduction per tile cost the feed more than the first rows gain; the
-// bf16x3 feeds had found the same.  The switch stays for A/B only: below 1024 the fed and the sequential order of a FORWARD
-// projection no longer give the same bits (the sequential order runs the one-chain kernel).
+// K in quarters for the first tiles of a feed.  K >= 1024 (the input-gradient feeds): since round 4.  K = 512 (the forward projections): measured
+// SLOWER in round 4 (forward sweeps 1.54 against 1.47 ms) and again early in round 5 -- with 4-byte accesses to the parked accumulators, which
+// cost the last arriver of a tile 56 us.  With 16-byte accesses (tools/dev/r5_fwd_quarters2.sh, one box): forward sweeps 1.45-1.49 / 1.43-1.44 /
+// 1.41-1.42 -> 1.40-1.42 / 1.38-1.40 / 1.36-1.38 ms with two or four groups in quarters.  A forward projection's first groups are therefore sums
+// of four K-quarters whenever the FEED kernel computes them, and the sequential order calls the feed kernel too (functional.py), so that both
+// orders keep giving the same bits.  PGASR_X6_QUARTER_K: A/B only.
 int x6_quarters(int K) {
     const char* e = getenv("PGASR_X6_QUARTER_K");
-    const int kmin = e ? atoi(e) : 1024;
+    const int kmin = e ? atoi(e) : 512;
     return (K >= kmin && K >= 16 * x6c::TK && K % (4 * x6c::TK) == 0) ? 4 : 1;
 }
 
@@ -984,7 +991,8 @@ extern "C" int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int 
         // sequential order run the same decomposition and give the same bits.
         const size_t room = (workspace_bytes - 1024) / ((size_t)x6c::SLAB_FLOATS * 4);          // parked accumulator sets
         const int total = mt * nt;
-        split8 = x6_split8_groups() * nt; split = x6_split_groups() * nt; split2 = x6_split2_groups() * nt;
+        if (K >= 1024) { split8 = x6_split8_groups() * nt; split = x6_split_groups() * nt; split2 = x6_split2_groups() * nt; }
+        else split = x6_fwd_split_groups() * nt;
         if (K % (8 * x6c::TK) || K < 32 * x6c::TK) { split += split8; split8 = 0; }
         if (split8 > total) split8 = total;
         if (split8 + split > total) split = total - split8;

@@ -403,7 +403,13 @@ class BLSTMLayerFn(torch.autograd.Function):
             if JOIN_FEED:
                 main.wait_stream(side)
         else:
-            if x3w:
+            if x3w and npl == 3 and hipops.x3w_feed_col_tiles(G, npl) > 0 and T * B * G * 4 < 2 ** 31:
+                # the sequential order of a six-product projection: the SAME kernel with the same decomposition as the fed order (its
+                # first tile groups are fixed-order sums of K-quarters, gemm_x6.hip), no XCD mask, before the sweep -- both orders give
+                # the same bits (like the input-gradient product in backward)
+                hipops.gemm_x3w_feed(x, prepacked.planes, gates, T * B, G, I, bias_perm, 0,
+                                     torch.zeros(2 * ((T * B + 255) // 256), dtype=torch.int32, device=x.device))
+            elif x3w:
                 hipops.gemm_x3w(x, prepacked.planes, gates, T * B, G, I, bias=bias_perm)
             else:
                 hipops.gemm(x, wih_perm, gates, M=T * B, N=G, K=I, transB=True, bias=bias_perm)
