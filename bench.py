@@ -505,6 +505,9 @@ def main():
     rehearse = os.environ.get("PGASR_BENCH_REHEARSE", "") == "1"
     if rehearse:
         local_rank = 0
+        # two processes with persistent kernels on ONE card can starve each other: say where the host is if a leg stops moving
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("PGASR_BENCH_STUCK_S", "240")), repeat=True, file=sys.stderr)
     if local_rank >= torch.cuda.device_count():      # a rank validates its own device (the parent does not touch the GPU)
         print(f"[bench] rank {rank} wants device {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
         sys.exit(2)
@@ -617,7 +620,7 @@ def main():
     hipops.profile_reset(False)
     hipops.lstm_assert_no_timeouts()      # every rank: a timed-out sweep would make the number meaningless
 
-    def timed_leg(fd, steps, warm):
+    def timed_leg(fd, steps, warm, name=""):
         """ms per step (max over ranks) of `steps` steps fed by `fd`, barrier-bracketed like the headline region."""
         for _ in range(warm):
             trainer.step(*fd.next()); fd.done()
@@ -632,18 +635,20 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             sec = float(tmax.item())
         hipops.lstm_assert_no_timeouts()
+        if rank == 0:
+            print(f"[bench] leg {name}: {sec / steps * 1e3:.3f} ms per step over {steps} steps", file=sys.stderr, flush=True)
         return sec / steps * 1e3
 
     # ---- legs that follow the headline region (all outside it; every rank runs them: they contain collectives) ----
     long_run = None
     if args.long_steps > 0:
-        lms = timed_leg(feeder, args.long_steps, 0)
+        lms = timed_leg(feeder, args.long_steps, 0, "long_run")
         long_run = {"steps": args.long_steps, "ms_per_step": lms, "value": B_PER_GPU * world / (lms * 1e-3),
                     "note": "same workload and feeder as the headline region, timed again over a longer run"}
     resident_leg = None
     if not bucketed and not args.no_extra_legs and args.h2d != "resident":
         # the same step with its inputs ALREADY in HBM (no staging copy in the step): what the PCIe-inclusive headline costs
-        rms = timed_leg(BatchFeeder(host, dev, "resident", trainer), 100, 5)
+        rms = timed_leg(BatchFeeder(host, dev, "resident", trainer), 100, 5, "inputs_resident")
         resident_leg = {"ms_per_step": rms, "utt_per_s": B_PER_GPU * world / (rms * 1e-3), "steps": 100, "warmup": 5,
                         "note": "inputs resident in HBM before the timed region; the headline `value` stages every step's batch from pinned "
                                 "host memory inside the timed region (model.py:227-230's .to(device) is part of the reference's step)"}
@@ -654,7 +659,7 @@ def main():
         pool = bucketed_pool(rank, world, n_batches=8, seed=0)
         bhost = [synth_batch(1000 + 17 * i + rank, lens, pin=True) for i, lens in enumerate(pool)]
         trainer.reward_decoder, trainer.beam_size = "beam", 16
-        bms = timed_leg(BatchFeeder(bhost, dev, args.h2d, trainer), 40, 8)
+        bms = timed_leg(BatchFeeder(bhost, dev, args.h2d, trainer), 40, 8, "bucketed")
         trainer.reward_decoder = "greedy"
         bframes = sum(sum(lens) for lens in pool) / len(pool)
         bucketed_leg = {"ms_per_step": bms, "utt_per_s": B_PER_GPU * world / (bms * 1e-3), "steps": 40, "warmup": 8,
