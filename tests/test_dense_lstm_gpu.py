@@ -84,6 +84,42 @@ def test_gemm_x3w_lds_dma(M, N, K, with_bias, with_dact, tile, monkeypatch):
     assert hipops.gemm_x3w_ok(M, N, K) and not hipops.gemm_x3w_ok(M, N + 1, K) and not hipops.gemm_x3w_ok(M, N, K + 8)
 
 
+@pytest.mark.parametrize("M,N,K,order,eighths,quarters,halves", [
+    (8192, 512, 2048, 1, 0, 16, 16),     # the input-gradient feed of the step as shipped: 16 groups in quarters, 16 in halves (every tile split here)
+    (8192, 512, 2048, 1, 2, 3, 4),       # eighths in front (A/B knob), then quarters, halves, whole tiles
+    (8192, 512, 2048, 0, 0, 0, 0),       # whole tiles only
+    (4000, 512, 2048, 1, 1, 1, 100),     # ragged last row tile; more halves asked for than tiles exist
+    (4096, 2048, 512, 0, 0, 2, 0),       # the forward projection: K = 512, two groups in quarters (PGASR_X6_FWD_SPLIT_GROUPS)
+    (4096, 2048, 512, 0, 0, 0, 0),
+])
+def test_gemm_x6w_feed_graded_head(M, N, K, order, eighths, quarters, halves, monkeypatch):
+    """pgasr_gemm_x6w_feed_f32 without a consumer (no XCD mask): the graded head of round 5 -- tile groups in K-eighths, -quarters and -halves
+    in front of the whole tiles, every tile the fixed-order sum of its parts (16-byte accesses to the parked accumulator sets) -- against fp64
+    at fp32-GEMM accuracy, every row tile counted exactly once per direction half, and the same bits on a second run."""
+    from policy_gradient_asr_amd import hipops
+    monkeypatch.setenv("PGASR_X6_SPLIT8_GROUPS", str(eighths))
+    monkeypatch.setenv("PGASR_X6_SPLIT_GROUPS", str(quarters))
+    monkeypatch.setenv("PGASR_X6_SPLIT2_GROUPS", str(halves))
+    monkeypatch.setenv("PGASR_X6_FWD_SPLIT_GROUPS", str(quarters))
+    g = torch.Generator().manual_seed(M + N + K + eighths)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    W = torch.randn(N, K, generator=g) * 0.1
+    bias = torch.randn(N, generator=g).to(DEV)
+    want = A.double().cpu() @ W.double().t() + bias.double().cpu()
+    pack = hipops.split_planes(W.to(DEV), planes=3, packed=True)
+    mt = (M + 255) // 256
+    outs = []
+    for _ in range(2):
+        C = torch.full((M, N), float("nan"), device=DEV)
+        done = torch.zeros(2 * mt, dtype=torch.int32, device=DEV)
+        hipops.gemm_x3w_feed(A, pack, C, M, N, K, bias, 0, done, order=order)
+        torch.cuda.synchronize()
+        assert done.cpu().tolist() == [hipops.x3w_feed_col_tiles(N, 3)] * (2 * mt)
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[0].cpu(), want) < 2e-6
+
+
 @pytest.mark.parametrize("M,N,K,with_bias,with_dact", [
     (300, 256, 64, True, True),         # four 16-deep steps: the prologue alone fills the ring; ragged M inside one row tile
     (777, 768, 80, True, False),        # five steps (3-unrolled loop ends mid-turn); ragged last row tile; three column tiles
