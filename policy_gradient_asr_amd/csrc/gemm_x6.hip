@@ -1008,9 +1008,15 @@ extern "C" int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int 
         const char* eh = getenv("PGASR_X6_HEAD_HELP");
         g.head_help = (eh ? atoi(eh) : X6_HEAD_HELP_DEFAULT) != 0 && split8 + split > 0;
     }
+    // PGASR_X6_FWD_FEED_GRID (A/B only): persistent workgroups of the masked pass of a FORWARD feed (K < 1024).  The forward phase has CUs to
+    // spare, and a sweep runs at the clock the GEMMs beside it leave (NOTES 0.46): does a thinner, longer feed cost the sweep less?  No
+    // (tools/dev/r5_fwd_feed_grid.sh, one box, forward sweeps of the f32 step): 256 workgroups 4.20-4.23 ms, 192: 4.23, 128: 4.20, 96: 4.18,
+    // 64: 5.94 (the sweep waits for its rows) -- the same GEMM energy beside the sweep costs it the same time, spread or not.
+    int grid0 = 256;
+    if (K < 1024 && xcc_busy) { const char* eg = getenv("PGASR_X6_FWD_FEED_GRID"); if (eg && atoi(eg) >= 16 && atoi(eg) <= 256) grid0 = atoi(eg); }
     for (int pass = 0; pass < 2; ++pass) {     // one persistent workgroup per CU; pass 1 ignores the busy counters
         if (pass == 1) g.xcc_busy = nullptr;
-        PGASR_LAUNCH_KERNEL(kern, dim3(256), dim3(x6c::THREADS), lds, st, g);
+        PGASR_LAUNCH_KERNEL(kern, dim3(pass == 0 ? grid0 : 256), dim3(x6c::THREADS), lds, st, g);
         PGASR_CHECK_LAUNCH();
     }
     return PGASR_OK;
