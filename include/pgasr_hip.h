@@ -39,7 +39,8 @@ typedef enum pgasr_status {
 
 /* 4 (round 3): pgasr_adam_step(guards, applied), pgasr_lstm_pack_weights(planes), the feed phases, and the streamed order:
  * pgasr_lstm_wgrad_slabs, pgasr_lstm_layer_bwd_streamed, pgasr_lstm_wgrads_streamed(+_workspace_bytes), pgasr_stream_gate_sum.
- * 7 (round 5): pgasr_stream_gate_report, pgasr_lstm_cell_f32; the sampler's counters for utterances beyond the global batch. */
+ * 7 (round 5): pgasr_stream_gate_report, pgasr_lstm_cell_f32, pgasr_gemm_x6w_feed_phase_f32 / _head_items; the sampler's counters for
+ * utterances beyond the global batch. */
 #define PGASR_ABI_VERSION 7
 
 int pgasr_abi_version(void);
@@ -295,6 +296,18 @@ int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int lda, const 
                             const unsigned short* Wmid, const unsigned short* Wlo, float* C, int ldc, const float* bias,
                             const unsigned* xcc_busy, unsigned* tiles_done, int order,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* The same feed in two launches (round 5).  phase 0: as pgasr_gemm_x6w_feed_f32.  phase 1, the HEAD: the queue head is zeroed and the
+ * pgasr_gemm_x6w_feed_head_items(M, N, K) K-split items at the front of the queue (the tile groups the consumer takes first) are computed
+ * one per workgroup, without an XCD mask -- to be issued on the feeding stream right behind the PREVIOUS sweep, before the consuming sweep
+ * has registered its XCDs (its launch, registration, the gate and the memset are then off the first rows' path).  phase 2, the rest: no
+ * memset, the persistent passes continue the same queue (same workspace, same arguments).  A phased feed needs the full
+ * pgasr_gemm_x6w_feed_workspace_bytes(); head_items == 0 (no split head for this shape): PGASR_ERR_UNSUPPORTED for phases 1 and 2.
+ * The decomposition -- hence every bit of C -- is that of phase 0. */
+int pgasr_gemm_x6w_feed_head_items(int M, int N, int K);
+int pgasr_gemm_x6w_feed_phase_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
+                                  const unsigned short* Wmid, const unsigned short* Wlo, float* C, int ldc, const float* bias,
+                                  const unsigned* xcc_busy, unsigned* tiles_done, int order, int phase,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* The reference's attention context (model.py:58-94, Attention.forward, AS EXECUTED -- csrc/attention.hip):
  *   ctx[q,k] = sum_i e[b,i,k] * (sum_r exp(d[q,r] e[b,i,k])) / (sum_k' exp(d[q,k] e[b,i,k'])),   b = q % B

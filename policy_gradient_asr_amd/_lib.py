@@ -111,6 +111,9 @@ SIGNATURES = {
     "pgasr_gemm_x6w_feed_col_tiles": (C.c_int, [C.c_int]),
     "pgasr_gemm_x6w_feed_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_ptr, c_ptr, c_ptr, c_f32p, C.c_int,
                                           c_f32p, c_ptr, c_ptr, C.c_int, c_ptr, C.c_size_t, c_ptr]),
+    "pgasr_gemm_x6w_feed_head_items": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "pgasr_gemm_x6w_feed_phase_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_ptr, c_ptr, c_ptr, c_f32p, C.c_int,
+                                                c_f32p, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, C.c_size_t, c_ptr]),
 }
 
 

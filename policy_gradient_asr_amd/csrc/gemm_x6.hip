@@ -498,7 +498,7 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
         __syncthreads();
         const unsigned before = *mailbox;
         __syncthreads();
-        if (before != parts - 1u) continue;
+        if (before != parts - 1u) { if (FEED && g.single) return; continue; }      // single: the head launch -- one work item per workgroup
         // total = ((p0 + p1) + p2) + .., whoever arrives last
         for (unsigned qq = 0; qq < parts; ++qq) {
 #pragma unroll
@@ -555,6 +555,7 @@ __global__ __launch_bounds__(THREADS) void gemm_x6c_kernel(DmaGemmArgs g) {
     __syncthreads();
     if (tid == 0)
         __hip_atomic_fetch_add(g.tiles_done + (tbx < (g.nt_count >> 1) ? 0 : g.mt_count) + tby, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (g.single) return;
 #ifdef PGASR_LSTM_DIAG
     {
         const unsigned nh_ = 8u * (unsigned)g.split8_tiles + 4u * (unsigned)g.split_tiles + 2u * (unsigned)g.split2_tiles;
@@ -961,15 +962,56 @@ extern "C" size_t pgasr_gemm_x6w_feed_workspace_bytes(void) { return 1024 + (siz
 // Column tiles per direction half that a six-product feed of an N-column product counts in tiles_done (the consumer's fed_need)
 extern "C" int pgasr_gemm_x6w_feed_col_tiles(int N) { return (N > 0 && N % (2 * x6c::TN) == 0) ? N / (2 * x6c::TN) : 0; }
 
-extern "C" int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
-                                       const unsigned short* Wmid, const unsigned short* Wlo, float* C, int ldc, const float* bias,
-                                       const unsigned* xcc_busy, unsigned* tiles_done, int order,
-                                       void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+// tiles of a feed's graded head (in queue order): eighths, quarters, halves -- a function of the product's shape, the knobs and the workspace only
+void x6_feed_splits(int mt, int nt, int K, size_t workspace_bytes, int& split8, int& split, int& split2) {
+    split8 = split = split2 = 0;
+    if (x6_quarters(K) != 4) return;
+    // THE GRADED HEAD (round 5, tools/dev/r5_feed_timeline.py): a whole tile of the input-gradient product (K = 2048) is 260-275 us on one CU and
+    // the sweep takes a tile group every ~11 us, so what the sweep waits for is not only its first rows: with sixteen groups in quarters and whole
+    // tiles behind them, group 16 was ready at ~340 us where the sweep wanted it at ~190 -- its second stall (20-40 us per cluster after the
+    // 120 us at step 0).  Groups in eighths first (PGASR_X6_SPLIT8_GROUPS), then quarters (PGASR_X6_SPLIT_GROUPS), then halves
+    // (PGASR_X6_SPLIT2_GROUPS), then whole tiles; every tile is the fixed-order sum of its parts, its position decides how many: the fed and the
+    // sequential order run the same decomposition and give the same bits.
+    const size_t room = (workspace_bytes - 1024) / ((size_t)x6c::SLAB_FLOATS * 4);          // parked accumulator sets
+    const int total = mt * nt;
+    if (K >= 1024) { split8 = x6_split8_groups() * nt; split = x6_split_groups() * nt; split2 = x6_split2_groups() * nt; }
+    else split = x6_fwd_split_groups() * nt;
+    if (K % (8 * x6c::TK) || K < 32 * x6c::TK) { split += split8; split8 = 0; }
+    if (split8 > total) split8 = total;
+    if (split8 + split > total) split = total - split8;
+    if (split8 + split + split2 > total) split2 = total - split8 - split;
+    while (split8 + split + split2 > X6_FEED_SPLIT_MAX || (size_t)(8 * split8 + 4 * split + 2 * split2) > room) {     // arrival words; slabs
+        if (split2 > 0) --split2; else if (split > 0) --split; else --split8;
+    }
+}
+}  // namespace
+
+// Work items of a HEAD launch (phase 1 of pgasr_gemm_x6w_feed_phase_f32): the eighth and quarter items of the feed's graded head; 0: none
+// (the shape has no split head, or more items than one workgroup per CU)
+extern "C" int pgasr_gemm_x6w_feed_head_items(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || pgasr_gemm_x6w_feed_col_tiles(N) == 0 || (K % x6c::TK)) return 0;
+    int s8, s4, s2;
+    x6_feed_splits((M + x6c::TM - 1) / x6c::TM, N / x6c::TN, K, pgasr_gemm_x6w_feed_workspace_bytes(), s8, s4, s2);
+    const int items = 8 * s8 + 4 * s4;
+    return items <= 256 ? items : 0;
+}
+
+// phase 0: the whole feed (memset of the queue head, masked pass, unmasked pass).  phase 1: the HEAD -- queue head zeroed, one workgroup per
+// eighth / quarter item, no XCD mask, every workgroup leaves after its item.  phase 2: the rest -- no memset, both passes continue the queue.
+// Round 5: the head goes onto the FEEDING stream right behind the previous sweep, while the consuming sweep is still being launched: its
+// workgroups need no registration of the sweep's XCDs, so the first row tiles no longer wait for launch -> registration -> gate -> memset.
+extern "C" int pgasr_gemm_x6w_feed_phase_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
+                                             const unsigned short* Wmid, const unsigned short* Wlo, float* C, int ldc, const float* bias,
+                                             const unsigned* xcc_busy, unsigned* tiles_done, int order, int phase,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
     if (!A || !Whi || (!Wmid != !Wlo) || !C || !tiles_done || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N) return PGASR_ERR_INVALID_ARG;
-    if (order < 0 || order > 1) return PGASR_ERR_INVALID_ARG;
+    if (order < 0 || order > 1 || phase < 0 || phase > 2) return PGASR_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < 1024) return PGASR_ERR_WORKSPACE;
     if (!x6w_shape_ok(M, N, K, A, lda, ldc, Whi, Wmid, Wlo) || pgasr_gemm_x6w_feed_col_tiles(N) == 0) return PGASR_ERR_UNSUPPORTED;
     if ((size_t)M * ldc * 4 >= ((size_t)1 << 31)) return PGASR_ERR_UNSUPPORTED;
+    // a phased feed sizes its head for the FULL workspace (pgasr_gemm_x6w_feed_head_items knows no other)
+    if (phase != 0 && workspace_bytes < pgasr_gemm_x6w_feed_workspace_bytes()) return PGASR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int mt = (M + x6c::TM - 1) / x6c::TM, nt = N / x6c::TN;
     const size_t lds = (size_t)x6c::LDS_BYTES + 16;
@@ -977,36 +1019,24 @@ extern "C" int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int 
     auto kern = var == 7 ? x6c::gemm_x6c_kernel<true, 7> : x6c::gemm_x6c_kernel<true, 0>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return PGASR_ERR_LAUNCH;
-    if (hipMemsetAsync(workspace, 0, 1024, st) != hipSuccess) return PGASR_ERR_LAUNCH;     // tile counter + arrival counters
-    // the first tile groups (16 time-ordered groups, at most X6_FEED_SPLIT_MAX tiles and what the workspace holds) are split into
-    // K-quarters: the sweep is waiting for exactly these
     const int quarters = x6_quarters(K);
-    int split8 = 0, split = 0, split2 = 0;
-    if (quarters == 4) {
-        // THE GRADED HEAD (round 5, tools/dev/r5_feed_timeline.py): a whole tile of the input-gradient product (K = 2048) is 260-275 us on one CU and
-        // the sweep takes a tile group every ~11 us, so what the sweep waits for is not only its first rows: with sixteen groups in quarters and whole
-        // tiles behind them, group 16 was ready at ~340 us where the sweep wanted it at ~190 -- its second stall (20-40 us per cluster after the
-        // 120 us at step 0).  Groups in eighths first (PGASR_X6_SPLIT8_GROUPS), then quarters (PGASR_X6_SPLIT_GROUPS), then halves
-        // (PGASR_X6_SPLIT2_GROUPS), then whole tiles; every tile is the fixed-order sum of its parts, its position decides how many: the fed and the
-        // sequential order run the same decomposition and give the same bits.
-        const size_t room = (workspace_bytes - 1024) / ((size_t)x6c::SLAB_FLOATS * 4);          // parked accumulator sets
-        const int total = mt * nt;
-        if (K >= 1024) { split8 = x6_split8_groups() * nt; split = x6_split_groups() * nt; split2 = x6_split2_groups() * nt; }
-        else split = x6_fwd_split_groups() * nt;
-        if (K % (8 * x6c::TK) || K < 32 * x6c::TK) { split += split8; split8 = 0; }
-        if (split8 > total) split8 = total;
-        if (split8 + split > total) split = total - split8;
-        if (split8 + split + split2 > total) split2 = total - split8 - split;
-        while (split8 + split + split2 > X6_FEED_SPLIT_MAX || (size_t)(8 * split8 + 4 * split + 2 * split2) > room) {     // arrival words; slabs
-            if (split2 > 0) --split2; else if (split > 0) --split; else --split8;
-        }
-    }
+    int split8, split, split2;
+    x6_feed_splits(mt, nt, K, phase != 0 ? pgasr_gemm_x6w_feed_workspace_bytes() : workspace_bytes, split8, split, split2);
+    const int head_items = 8 * split8 + 4 * split;
+    if (phase != 0 && (head_items <= 0 || head_items > 256)) return PGASR_ERR_UNSUPPORTED;
+    if (phase != 2 && hipMemsetAsync(workspace, 0, 1024, st) != hipSuccess) return PGASR_ERR_LAUNCH;     // tile counter + arrival counters
     DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, nullptr, 0.f, (unsigned*)workspace, xcc_busy, tiles_done, mt, nt, order,
                   quarters, split, (float*)((char*)workspace + 1024), (unsigned*)workspace + 64, 0, Wmid};
     g.split8_tiles = split8; g.split2_tiles = split2; g.slab_count = 8 * split8 + 4 * split + 2 * split2;
+    if (phase == 1) {
+        g.single = 1; g.xcc_busy = nullptr; g.head_help = 0;
+        PGASR_LAUNCH_KERNEL(kern, dim3((unsigned)head_items), dim3(x6c::THREADS), lds, st, g);
+        PGASR_CHECK_LAUNCH();
+        return PGASR_OK;
+    }
     {   // PGASR_X6_HEAD_HELP (read at every call; a speed hint, the same bits either way): workgroups on the sweep's XCDs take K-split head items
         const char* eh = getenv("PGASR_X6_HEAD_HELP");
-        g.head_help = (eh ? atoi(eh) : X6_HEAD_HELP_DEFAULT) != 0 && split8 + split > 0;
+        g.head_help = (eh ? atoi(eh) : X6_HEAD_HELP_DEFAULT) != 0 && split8 + split > 0 && phase == 0;
     }
     // PGASR_X6_FWD_FEED_GRID (A/B only): persistent workgroups of the masked pass of a FORWARD feed (K < 1024).  The forward phase has CUs to
     // spare, and a sweep runs at the clock the GEMMs beside it leave (NOTES 0.46): does a thinner, longer feed cost the sweep less?  No
@@ -1020,6 +1050,13 @@ extern "C" int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int 
         PGASR_CHECK_LAUNCH();
     }
     return PGASR_OK;
+}
+
+extern "C" int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
+                                       const unsigned short* Wmid, const unsigned short* Wlo, float* C, int ldc, const float* bias,
+                                       const unsigned* xcc_busy, unsigned* tiles_done, int order,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    return pgasr_gemm_x6w_feed_phase_f32(M, N, K, A, lda, Whi, Wmid, Wlo, C, ldc, bias, xcc_busy, tiles_done, order, 0, workspace, workspace_bytes, stream);
 }
 
 // ---- internal: the six-product TN kernel behind pgasr_lstm_wgrads_streamed(planes = 3) (same contract as pgasr_internal_tn256_launch) ----

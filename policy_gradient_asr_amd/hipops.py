@@ -620,8 +620,23 @@ def x3w_feed_col_tiles(N, planes=2):
 FEED_HEAD_GROUPS = int(_os_environ_get("PGASR_FEED_HEAD", "0"))
 
 
+# Six-product feeds (round 5): the K-split items at the head of the queue as a launch of their own on the FEEDING stream, right behind the
+# previous sweep and beside the launch of the consuming one (BLSTMLayerFn) -- not in front of the sweep on its own stream like the bf16x3 head
+# above, which cost the critical stream what it saved.  OFF: measured (tools/dev/r5_side_head.sh, one box, A/B/A/B): f32 step 9.67 / 9.75 ms
+# without, 10.00 / 9.90 with -- the head's items do start ~35 us earlier, but the gate and the persistent launch sit behind the head kernel on
+# the same stream, so the halves and whole tiles start ~40 us LATER and the sweep waits for those instead (forward sweeps +0.04 ms each).  A
+# head on a stream of its own would need pre-zeroed queue words per feed and one more vetted hardware queue per step; not built.
+X6_SIDE_HEAD = _os_environ_get("PGASR_X6_SIDE_HEAD", "0") != "0"
+
+
+def x6w_feed_side_head_items(M, N, K):
+    """Work items of the head launch of a six-product feed (0: the shape has no K-split head, or the switch is off)."""
+    return int(_lib.load().pgasr_gemm_x6w_feed_head_items(int(M), int(N), int(K))) if X6_SIDE_HEAD else 0
+
+
 def x3w_feed_head_items(N, K, groups=None, planes=2):
-    """Work items of a feed's HEAD launch (0: this shape / tile structure has none; the six-product feeds have none)."""
+    """Work items of a feed's HEAD launch IN FRONT of the sweep on the sweep's stream (0: this shape / tile structure has none; the
+    six-product feeds have none of that kind -- theirs goes onto the feeding stream, ``x6w_feed_side_head_items``)."""
     groups = FEED_HEAD_GROUPS if groups is None else groups
     if planes == 3:
         return 0
@@ -640,15 +655,15 @@ def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done, order=0, ph
     if tiles_done.dtype != torch.int32 or tiles_done.numel() < 2 * ((M + 255) // 256):
         raise _lib.PgasrError("gemm_x3w_feed: tiles_done must hold 2 * ceil(M/256) int32 words")
     if len(planes) == 3:
-        if phase != 0:
-            raise _lib.PgasrError("gemm_x3w_feed: the six-product feeds have no head launch")
+        if phase == 2 and ws is None:
+            raise _lib.PgasrError("gemm_x3w_feed: phase 2 continues the queue of a phase-1 call: pass its workspace")
         if ws is None:
             ws = _workspace(lib.pgasr_gemm_x6w_feed_workspace_bytes(), C.device, "x6w_feed")
         with _timed("gemm_feed_x6c"):        # on the feeding stream: the time includes what the persistent workgroups wait for the sweep
-            st = lib.pgasr_gemm_x6w_feed_f32(M, N, K, A.data_ptr(), K, *_plane_ptrs(planes), C.data_ptr(), N, _p(bias),
-                                             busy_ptr, tiles_done.data_ptr(), int(order), _p(ws), ws.numel(), _stream())
-        _lib.check(st, "pgasr_gemm_x6w_feed_f32")
-        return C
+            st = lib.pgasr_gemm_x6w_feed_phase_f32(M, N, K, A.data_ptr(), K, *_plane_ptrs(planes), C.data_ptr(), N, _p(bias),
+                                                   busy_ptr, tiles_done.data_ptr(), int(order), int(phase), _p(ws), ws.numel(), _stream())
+        _lib.check(st, "pgasr_gemm_x6w_feed_phase_f32")
+        return ws if phase == 1 else C
     if ws is None:
         ws = _workspace(lib.pgasr_gemm_x3w_feed_workspace_bytes(), C.device, "x3w_feed")
     with _timed("gemm_feed_x3w"):

@@ -12,6 +12,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def _lib_load():
+    from policy_gradient_asr_amd import _lib
+    return _lib.load()
+
+
 def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
@@ -118,6 +123,20 @@ def test_gemm_x6w_feed_graded_head(M, N, K, order, eighths, quarters, halves, mo
         outs.append(C)
     assert torch.equal(outs[0], outs[1])
     assert rel_err(outs[0].cpu(), want) < 2e-6
+    # the same feed in two launches (pgasr_gemm_x6w_feed_phase_f32: the K-split head one item per workgroup, then the rest): the same bits
+    items = int(_lib_load().pgasr_gemm_x6w_feed_head_items(M, N, K))
+    assert 0 <= items <= 256 and (items > 0) == (eighths + quarters > 0)
+    if items > 0:
+        C = torch.full((M, N), float("nan"), device=DEV)
+        done = torch.zeros(2 * mt, dtype=torch.int32, device=DEV)
+        ws = hipops.gemm_x3w_feed(A, pack, C, M, N, K, bias, 0, done, order=order, phase=1)
+        hipops.gemm_x3w_feed(A, pack, C, M, N, K, bias, 0, done, order=order, phase=2, ws=ws)
+        torch.cuda.synchronize()
+        assert done.cpu().tolist() == [hipops.x3w_feed_col_tiles(N, 3)] * (2 * mt)
+        assert torch.equal(C, outs[0])
+    else:
+        with pytest.raises(Exception):
+            hipops.gemm_x3w_feed(A, pack, torch.empty(M, N, device=DEV), M, N, K, bias, 0, torch.zeros(2 * mt, dtype=torch.int32, device=DEV), order=order, phase=1)
 
 
 @pytest.mark.parametrize("M,N,K,with_bias,with_dact", [
