@@ -302,11 +302,14 @@ int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int lda, const 
  * has registered its XCDs (its launch, registration, the gate and the memset are then off the first rows' path).  phase 2, the rest: no
  * memset, the persistent passes continue the same queue (same workspace, same arguments).  A phased feed needs the full
  * pgasr_gemm_x6w_feed_workspace_bytes(); head_items == 0 (no split head for this shape): PGASR_ERR_UNSUPPORTED for phases 1 and 2.
+ * ctrl (optional): 256 words zeroed by the CALLER for this feed -- the queue and arrival counters live there instead of the workspace's
+ * first KB and no phase issues a memset, so phases 1 and 2 may be issued on two streams (the head right behind the previous sweep, the rest
+ * behind the consuming sweep's registration) and draw from the one queue side by side.
  * The decomposition -- hence every bit of C -- is that of phase 0. */
 int pgasr_gemm_x6w_feed_head_items(int M, int N, int K);
 int pgasr_gemm_x6w_feed_phase_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
                                   const unsigned short* Wmid, const unsigned short* Wlo, float* C, int ldc, const float* bias,
-                                  const unsigned* xcc_busy, unsigned* tiles_done, int order, int phase,
+                                  const unsigned* xcc_busy, unsigned* tiles_done, int order, int phase, unsigned* ctrl,
                                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* The reference's attention context (model.py:58-94, Attention.forward, AS EXECUTED -- csrc/attention.hip):

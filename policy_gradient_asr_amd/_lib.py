@@ -113,7 +113,7 @@ SIGNATURES = {
                                           c_f32p, c_ptr, c_ptr, C.c_int, c_ptr, C.c_size_t, c_ptr]),
     "pgasr_gemm_x6w_feed_head_items": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pgasr_gemm_x6w_feed_phase_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_ptr, c_ptr, c_ptr, c_f32p, C.c_int,
-                                                c_f32p, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, C.c_size_t, c_ptr]),
+                                                c_f32p, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, c_ptr, C.c_size_t, c_ptr]),
 }
 
 

@@ -1003,7 +1003,7 @@ extern "C" int pgasr_gemm_x6w_feed_head_items(int M, int N, int K) {
 // workgroups need no registration of the sweep's XCDs, so the first row tiles no longer wait for launch -> registration -> gate -> memset.
 extern "C" int pgasr_gemm_x6w_feed_phase_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
                                              const unsigned short* Wmid, const unsigned short* Wlo, float* C, int ldc, const float* bias,
-                                             const unsigned* xcc_busy, unsigned* tiles_done, int order, int phase,
+                                             const unsigned* xcc_busy, unsigned* tiles_done, int order, int phase, unsigned* ctrl,
                                              void* workspace, size_t workspace_bytes, void* stream) {
     if (!A || !Whi || (!Wmid != !Wlo) || !C || !tiles_done || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N) return PGASR_ERR_INVALID_ARG;
     if (order < 0 || order > 1 || phase < 0 || phase > 2) return PGASR_ERR_INVALID_ARG;
@@ -1024,9 +1024,12 @@ extern "C" int pgasr_gemm_x6w_feed_phase_f32(int M, int N, int K, const float* A
     x6_feed_splits(mt, nt, K, phase != 0 ? pgasr_gemm_x6w_feed_workspace_bytes() : workspace_bytes, split8, split, split2);
     const int head_items = 8 * split8 + 4 * split;
     if (phase != 0 && (head_items <= 0 || head_items > 256)) return PGASR_ERR_UNSUPPORTED;
-    if (phase != 2 && hipMemsetAsync(workspace, 0, 1024, st) != hipSuccess) return PGASR_ERR_LAUNCH;     // tile counter + arrival counters
-    DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, nullptr, 0.f, (unsigned*)workspace, xcc_busy, tiles_done, mt, nt, order,
-                  quarters, split, (float*)((char*)workspace + 1024), (unsigned*)workspace + 64, 0, Wmid};
+    // ctrl != NULL: 256 words the CALLER has zeroed for this feed (tile counter at 0, arrival counters from word 64) -- no memset in any phase,
+    // so the head and the rest may be issued on two streams and draw from the one queue side by side
+    if (!ctrl && phase != 2 && hipMemsetAsync(workspace, 0, 1024, st) != hipSuccess) return PGASR_ERR_LAUNCH;     // tile counter + arrival counters
+    unsigned* cw = ctrl ? ctrl : (unsigned*)workspace;
+    DmaGemmArgs g{A, Whi, Wlo, C, M, N, K, lda, ldc, bias, nullptr, 0.f, cw, xcc_busy, tiles_done, mt, nt, order,
+                  quarters, split, (float*)((char*)workspace + 1024), cw + 64, 0, Wmid};
     g.split8_tiles = split8; g.split2_tiles = split2; g.slab_count = 8 * split8 + 4 * split + 2 * split2;
     if (phase == 1) {
         g.single = 1; g.xcc_busy = nullptr; g.head_help = 0;
@@ -1036,7 +1039,7 @@ extern "C" int pgasr_gemm_x6w_feed_phase_f32(int M, int N, int K, const float* A
     }
     {   // PGASR_X6_HEAD_HELP (read at every call; a speed hint, the same bits either way): workgroups on the sweep's XCDs take K-split head items
         const char* eh = getenv("PGASR_X6_HEAD_HELP");
-        g.head_help = (eh ? atoi(eh) : X6_HEAD_HELP_DEFAULT) != 0 && split8 + split > 0 && phase == 0;
+        g.head_help = (eh ? atoi(eh) : X6_HEAD_HELP_DEFAULT) != 0 && split8 + split > 0 && (phase == 0 || ctrl != nullptr);
     }
     // PGASR_X6_FWD_FEED_GRID (A/B only): persistent workgroups of the masked pass of a FORWARD feed (K < 1024).  The forward phase has CUs to
     // spare, and a sweep runs at the clock the GEMMs beside it leave (NOTES 0.46): does a thinner, longer feed cost the sweep less?  No
@@ -1056,7 +1059,7 @@ extern "C" int pgasr_gemm_x6w_feed_f32(int M, int N, int K, const float* A, int 
                                        const unsigned short* Wmid, const unsigned short* Wlo, float* C, int ldc, const float* bias,
                                        const unsigned* xcc_busy, unsigned* tiles_done, int order,
                                        void* workspace, size_t workspace_bytes, void* stream) {
-    return pgasr_gemm_x6w_feed_phase_f32(M, N, K, A, lda, Whi, Wmid, Wlo, C, ldc, bias, xcc_busy, tiles_done, order, 0, workspace, workspace_bytes, stream);
+    return pgasr_gemm_x6w_feed_phase_f32(M, N, K, A, lda, Whi, Wmid, Wlo, C, ldc, bias, xcc_busy, tiles_done, order, 0, nullptr, workspace, workspace_bytes, stream);
 }
 
 // ---- internal: the six-product TN kernel behind pgasr_lstm_wgrads_streamed(planes = 3) (same contract as pgasr_internal_tn256_launch) ----

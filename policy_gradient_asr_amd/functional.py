@@ -385,20 +385,13 @@ class BLSTMLayerFn(torch.autograd.Function):
             ws_feed = hipops.gemm_x3w_feed(x, prepacked.planes, gates, T * B, G, I, bias_perm, 0, done, phase=1) if head else None
             zeroed = torch.cuda.Event()
             zeroed.record()
-            side.wait_event(zeroed)
-            # SIDE HEAD (six-product feeds, round 5): the K-split items at the head of the queue go onto the FEEDING stream now -- behind the
-            # previous layer's sweep (the event), beside the launch of this one: they need no registration of this sweep's XCDs, so the first
-            # row tiles do not wait for launch -> registration -> gate -> memset (the feed used to start ~40 us after the previous sweep's end)
-            side_head = (not head) and npl == 3 and hipops.x6w_feed_side_head_items(T * B, G, I) > 0
-            if side_head:
-                with torch.cuda.stream(side):
-                    ws_feed = hipops.gemm_x3w_feed(x, prepacked.planes, gates, T * B, G, I, bias_perm, 0, done, phase=1)
             hipops.lstm_layer_fwd(gates, out, cbuf, pack_f, lengths, T, B, fed=done, fed_need=hipops.x3w_feed_col_tiles(G, npl), **dkw)
+            side.wait_event(zeroed)
             busy = hipops.lstm_busy_ptr(T, B, False, x.device)
             with torch.cuda.stream(side):
                 hipops.stream_gate(busy)
                 hipops.gemm_x3w_feed(x, prepacked.planes, gates, T * B, G, I, bias_perm, busy if grad_overlap.confine_feed else 0, done,
-                                     phase=2 if (head or side_head) else 0, ws=ws_feed)
+                                     phase=2 if head else 0, ws=ws_feed)
             if ws_feed is not None:
                 streams.hold(ws_feed, side)
             for t_ in (x, gates, done, bias_perm) + tuple(prepacked.planes):
@@ -470,11 +463,6 @@ class BLSTMLayerFn(torch.autograd.Function):
             if grad_overlap.enabled and rec["head"]():
                 before = torch.cuda.Event()       # the side stream's part must come behind the head (one queue)
                 before.record()
-            elif grad_overlap.enabled and before is not None:
-                side_ = grad_overlap.side_stream()
-                side_.wait_event(before)          # the layer above's sweep has ended: its dgates are complete
-                with torch.cuda.stream(side_):
-                    rec["side_head"]()
             sweep_ws, dbias_part = hipops.lstm_layer_bwd(gates, out, cbuf, dout, pack_b, lengths, T, B, want_dbias=True,
                                                          fed=rec["done"], fed_need=rec["need"], drop=rec["drop"], slab=slab)
         else:
@@ -527,14 +515,6 @@ class BLSTMLayerFn(torch.autograd.Function):
                     return True
                 return False
 
-            def side_head(dg=dg, dx=dx, done=done, planes_t=planes_t):
-                """On the FEEDING stream, behind this layer's sweep and beside the launch of the consuming one (six-product feeds; see forward)."""
-                if not feed_ws and npl == 3 and hipops.x6w_feed_side_head_items(T * B, I, G) > 0:
-                    feed_ws.append(hipops.gemm_x3w_feed(dg, planes_t, dx, T * B, I, G, None, 0, done, order=1, phase=1))
-                    side_ = torch.cuda.current_stream()
-                    for t_ in (dg, dx, done) + tuple(planes_t) + tuple(feed_ws):
-                        streams.hold(t_, side_)
-
             def launch(busy_ptr, dg=dg, dx=dx, done=done, planes_t=planes_t):
                 hipops.gemm_x3w_feed(dg, planes_t, dx, T * B, I, G, None, busy_ptr if grad_overlap.confine_feed else 0, done, order=1,
                                      phase=2 if feed_ws else 0, ws=feed_ws[0] if feed_ws else None)
@@ -542,7 +522,7 @@ class BLSTMLayerFn(torch.autograd.Function):
                 for t_ in (dg, dx, done) + tuple(planes_t) + tuple(feed_ws):
                     streams.hold(t_, side_)
             grad_overlap._deferred[dx.data_ptr()] = {"dx": dx, "done": done, "need": hipops.x3w_feed_col_tiles(I, npl), "drop": None,
-                                                     "launch": launch, "head": head, "side_head": side_head}
+                                                     "launch": launch, "head": head}
         elif ctx.needs_input_grad[0]:
             dx = torch.empty(T, B, I, dtype=torch.float32, device=dev)
             if (ctx.sweep_follows and not ctx.has_dact and ctx.planes_t is not None and hipops.gemm_x3w_ok(T * B, I, G, planes=npl)

@@ -620,30 +620,25 @@ def x3w_feed_col_tiles(N, planes=2):
 FEED_HEAD_GROUPS = int(_os_environ_get("PGASR_FEED_HEAD", "0"))
 
 
-# Six-product feeds (round 5): the K-split items at the head of the queue as a launch of their own on the FEEDING stream, right behind the
-# previous sweep and beside the launch of the consuming one (BLSTMLayerFn) -- not in front of the sweep on its own stream like the bf16x3 head
-# above, which cost the critical stream what it saved.  OFF: measured (tools/dev/r5_side_head.sh, one box, A/B/A/B): f32 step 9.67 / 9.75 ms
-# without, 10.00 / 9.90 with -- the head's items do start ~35 us earlier, but the gate and the persistent launch sit behind the head kernel on
-# the same stream, so the halves and whole tiles start ~40 us LATER and the sweep waits for those instead (forward sweeps +0.04 ms each).  A
-# head on a stream of its own would need pre-zeroed queue words per feed and one more vetted hardware queue per step; not built.
-X6_SIDE_HEAD = _os_environ_get("PGASR_X6_SIDE_HEAD", "0") != "0"
-
-
-def x6w_feed_side_head_items(M, N, K):
-    """Work items of the head launch of a six-product feed (0: the shape has no K-split head, or the switch is off)."""
-    return int(_lib.load().pgasr_gemm_x6w_feed_head_items(int(M), int(N), int(K))) if X6_SIDE_HEAD else 0
+# Six-product feeds (round 5): their K-split head can be a launch of its own (``gemm_x3w_feed(phase=1 / 2, ctrl=...)``,
+# pgasr_gemm_x6w_feed_phase_f32) -- right behind the previous sweep instead of behind the consuming sweep's registration, gate and memset
+# (the feed otherwise starts ~40 us after the previous sweep's end).  Wired into BLSTMLayerFn twice and measured (tools/dev/r5_side_head.sh, f32
+# step, A/B/A/B on one box each): head on the feeding stream 10.00 / 9.90 ms against 9.67 / 9.75 (gate and persistent launch queue behind the
+# head kernel: the whole tiles start ~40 us later and the sweep waits for those); head on a stream of its own with caller-zeroed queue words
+# 9.79 / 9.785 (9.76 with four or six forward groups in the head) against 9.77 / 9.72 -- nothing.  The wiring was taken out again; the entry
+# point stays, covered by test_gemm_x6w_feed_graded_head (same bits as the single launch).
 
 
 def x3w_feed_head_items(N, K, groups=None, planes=2):
     """Work items of a feed's HEAD launch IN FRONT of the sweep on the sweep's stream (0: this shape / tile structure has none; the
-    six-product feeds have none of that kind -- theirs goes onto the feeding stream, ``x6w_feed_side_head_items``)."""
+    six-product feeds have none of that kind)."""
     groups = FEED_HEAD_GROUPS if groups is None else groups
     if planes == 3:
         return 0
     return int(_lib.load().pgasr_gemm_x3w_feed_head_items(int(N), int(K), int(groups))) if groups > 0 else 0
 
 
-def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done, order=0, phase=0, ws=None):
+def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done, order=0, phase=0, ws=None, ctrl=None):
     """``gemm_x3w`` in feed-ahead mode on the CURRENT stream (see include/pgasr_hip.h, pgasr_gemm_x3w_feed_f32).
     phase 1 (head, on the sweep's stream in front of the sweep) returns the workspace that the phase-2 call (rest, on
     the feeding stream) must be given as ``ws``: both work on one queue."""
@@ -660,8 +655,10 @@ def gemm_x3w_feed(A, planes, C, M, N, K, bias, busy_ptr, tiles_done, order=0, ph
         if ws is None:
             ws = _workspace(lib.pgasr_gemm_x6w_feed_workspace_bytes(), C.device, "x6w_feed")
         with _timed("gemm_feed_x6c"):        # on the feeding stream: the time includes what the persistent workgroups wait for the sweep
+            if ctrl is not None and (ctrl.dtype != torch.int32 or ctrl.numel() < 256 or not ctrl.is_contiguous()):
+                raise _lib.PgasrError("gemm_x3w_feed: ctrl = 256 zeroed int32 words")
             st = lib.pgasr_gemm_x6w_feed_phase_f32(M, N, K, A.data_ptr(), K, *_plane_ptrs(planes), C.data_ptr(), N, _p(bias),
-                                                   busy_ptr, tiles_done.data_ptr(), int(order), int(phase), _p(ws), ws.numel(), _stream())
+                                                   busy_ptr, tiles_done.data_ptr(), int(order), int(phase), _p(ctrl), _p(ws), ws.numel(), _stream())
         _lib.check(st, "pgasr_gemm_x6w_feed_phase_f32")
         return ws if phase == 1 else C
     if ws is None:

@@ -134,6 +134,14 @@ def test_gemm_x6w_feed_graded_head(M, N, K, order, eighths, quarters, halves, mo
         torch.cuda.synchronize()
         assert done.cpu().tolist() == [hipops.x3w_feed_col_tiles(N, 3)] * (2 * mt)
         assert torch.equal(C, outs[0])
+        # .. and with the queue words in a block the CALLER zeroed (no memset in either launch: they may go onto two streams)
+        C2 = torch.full((M, N), float("nan"), device=DEV)
+        done = torch.zeros(2 * mt, dtype=torch.int32, device=DEV)
+        ctrl = torch.zeros(256, dtype=torch.int32, device=DEV)
+        ws = hipops.gemm_x3w_feed(A, pack, C2, M, N, K, bias, 0, done, order=order, phase=1, ctrl=ctrl)
+        hipops.gemm_x3w_feed(A, pack, C2, M, N, K, bias, 0, done, order=order, phase=2, ws=ws, ctrl=ctrl)
+        torch.cuda.synchronize()
+        assert torch.equal(C2, outs[0]) and int(ctrl[0]) >= mt * (N // 256)
     else:
         with pytest.raises(Exception):
             hipops.gemm_x3w_feed(A, pack, torch.empty(M, N, device=DEV), M, N, K, bias, 0, torch.zeros(2 * mt, dtype=torch.int32, device=DEV), order=order, phase=1)
