@@ -999,8 +999,10 @@ extern "C" int pgasr_gemm_x6w_feed_head_items(int M, int N, int K) {
 
 // phase 0: the whole feed (memset of the queue head, masked pass, unmasked pass).  phase 1: the HEAD -- queue head zeroed, one workgroup per
 // eighth / quarter item, no XCD mask, every workgroup leaves after its item.  phase 2: the rest -- no memset, both passes continue the queue.
-// Round 5: the head goes onto the FEEDING stream right behind the previous sweep, while the consuming sweep is still being launched: its
-// workgroups need no registration of the sweep's XCDs, so the first row tiles no longer wait for launch -> registration -> gate -> memset.
+// The head needs no registration of the consuming sweep's XCDs, so it can be issued right behind the PREVIOUS sweep (the single launch starts
+// ~40 us after that sweep's end: event -> prepare -> sweep -> registration -> gate -> memset -> launch).  Round 5 wired it into the step twice --
+// on the feeding stream, and on a stream of its own with caller-zeroed queue words -- and measured nothing to gain (hipops.py, NOTES 0.46);
+// the step uses phase 0.
 extern "C" int pgasr_gemm_x6w_feed_phase_f32(int M, int N, int K, const float* A, int lda, const unsigned short* Whi,
                                              const unsigned short* Wmid, const unsigned short* Wlo, float* C, int ldc, const float* bias,
                                              const unsigned* xcc_busy, unsigned* tiles_done, int order, int phase, unsigned* ctrl,
