@@ -745,6 +745,12 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_fwd_kernel(LstmArgs a) {
             if (aborted) break;
         }
     } else {
+#ifdef PGASR_SWEEP_PRIO
+        // A/B only: the compute waves of SIMD 0 / 1 share their instruction arbiter with the loader / storer wave.  Round 5 (tools/dev/r5_sweep_prio.sh,
+        // f32 step, A/B/C/A/B by library): priority 3 forward sweeps 4.17-4.21 ms against 4.20-4.23, backward 4.42-4.45 against 4.38-4.41; priority 1
+        // 4.18 / 4.44 -- nothing either way, not built into the product
+        __builtin_amdgcn_s_setprio(PGASR_SWEEP_PRIO);
+#endif
         // one step of a compute wave; `first` is a literal at both call sites, so the step-0 special cases fold away
         auto compute_step = [&](const int step, const bool first) -> int {
             const int t = step_t(step);
@@ -1048,6 +1054,9 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_bwd_kernel(LstmArgs a) {
         }
         if (nslab && !aborted) publish();       // the last slab (k_pub == number of slabs here)
     } else {
+#ifdef PGASR_SWEEP_PRIO
+        __builtin_amdgcn_s_setprio(PGASR_SWEEP_PRIO);     // A/B only (see lstm_fwd_kernel)
+#endif
         STAMP_DECL;        // diagnostic build: 0 loop top + pre-poll cell work, 1 poll, 2 cell gradient + plane stores, 3 LDS barrier, 4 MFMA + publish
         auto compute_step = [&](const int step, const bool first) -> int {
             const int t = step_t(step);
